@@ -1,0 +1,223 @@
+"""Generate golden vectors from the UNMODIFIED reference (/root/reference) -- builder container only.
+
+TEST INFRASTRUCTURE.  Run:  ``python oracle/make_golden.py [--only tiny|full|all]``
+Writes small fixtures into ``tests/golden/`` (committed), because /root/reference does not exist on the GPU
+box.  The reference modules are imported as-is with three process-local shims:
+  1. stub ``timm.models.layers`` / ``timm.models.registry`` (convnext.py:12-13 imports; timm not installed)
+  2. ``torch.hub.load_state_dict_from_url`` -> ``{"model": {}}`` (convnext.py:154-157 downloads weights)
+  3. PyYAML instead of OmegaConf for configs/*.yaml
+``utils/model.py`` cannot be imported (needs CLIP weights), so its two tiny functions used by the samplers
+(``set_alpha_scale`` :78-81, ``alpha_generator`` :83-117) are restated here.
+
+Weights are synthetic and key-name-seeded (instancediffusion_amd/synth.py), loaded with load_state_dict, so
+the oracle / HIP engine can regenerate identical parameters anywhere.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import types
+from copy import deepcopy
+from functools import partial
+
+import numpy as np
+import torch
+import yaml
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def install_shims():
+    layers = types.ModuleType("timm.models.layers")
+    layers.trunc_normal_ = lambda t, std=1.0, **k: torch.nn.init.trunc_normal_(t, std=std)
+
+    class DropPath(torch.nn.Identity):
+        def __init__(self, *a, **k):
+            super().__init__()
+    layers.DropPath = DropPath
+    registry = types.ModuleType("timm.models.registry")
+    registry.register_model = lambda f: f
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers,
+                        "timm.models.registry": registry})
+    torch.hub.load_state_dict_from_url = lambda *a, **k: {"model": {}}
+    # the reference tree must win over this repo's same-named ``ldm`` mirror package
+    sys.path = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+
+
+def ref_set_alpha_scale(model, alpha_scale):            # utils/model.py:78-81
+    from ldm.modules.attention import GatedSelfAttentionDense
+    for m in model.modules():
+        if type(m) == GatedSelfAttentionDense:
+            m.scale = alpha_scale
+
+
+def ref_alpha_generator(length, type=None):             # utils/model.py:83-117
+    if type is None:
+        type = [1, 0, 0]
+    assert len(type) == 3 and type[0] + type[1] + type[2] == 1
+    s0 = int(type[0] * length)
+    s1 = int(type[1] * length)
+    s2 = length - s0 - s1
+    decay = list(np.arange(start=0, stop=1, step=1 / s1)[::-1]) if s1 != 0 else []
+    al = [1] * s0 + decay + [0] * s2
+    assert len(al) == length
+    return al
+
+
+# reduced architectures for fast tests.  "tiny": 64 base channels (head dims 8/16/32).  "mid": the real
+# 320/640/1280 widths (head dims 40/80/160) but 3 levels x 1 ResBlock, run on 16x16 latents.
+VARIANTS = {
+    "full": {},
+    "tiny": dict(model=dict(model_channels=64), tok=dict(mid_dim=256)),
+    "mid": dict(model=dict(channel_mult=[1, 2, 4], num_res_blocks=1), tok=dict(mid_dim=512)),
+}
+
+
+def load_cfg(name: str, variant: str):
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", name)))
+    v = VARIANTS[variant]
+    cfg["model"]["params"].update(v.get("model", {}))
+    cfg["model"]["params"]["grounding_tokenizer"]["params"].update(v.get("tok", {}))
+    cfg["model"]["params"]["use_checkpoint"] = False
+    return cfg
+
+
+def build(cfg, salt=0):
+    from ldm.util import instantiate_from_config
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("idf_synth", os.path.join(REPO, "instancediffusion_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    model = instantiate_from_config(cfg["model"]).eval()
+    schema = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(schema, salt)
+    model.load_state_dict(sd, strict=True)
+    gi = instantiate_from_config(cfg["grounding_tokenizer_input"])
+    model.grounding_tokenizer_input = gi
+    diffusion = instantiate_from_config(cfg["diffusion"])
+    return model, gi, diffusion, schema, synth
+
+
+def fp(t: torch.Tensor):
+    t = t.detach().float()
+    return dict(mean=float(t.mean()), std=float(t.std()), absmax=float(t.abs().max()),
+                head=t.flatten()[:32].clone(), shape=list(t.shape))
+
+
+def patch_first_conv(model, first_conv_sd):
+    """restore_first_conv_from_SD (openaimodel.py:469-480) reads a cwd-relative .pth; for synthetic weights we
+    feed it the synthetic file contents through th.load by writing a temp file in a temp cwd."""
+    import tempfile
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "pretrained"))
+    torch.save(first_conv_sd, os.path.join(d, "pretrained", "SD_v1_5_input_conv_weight_bias.pth"))
+    os.chdir(d)
+
+
+@torch.no_grad()
+def gen_case(tag: str, cfg_name: str, variant: str, latent: int, n_boxes: int, batch: int, *, boxes="rand",
+             alpha_type=(0.6, 0.0, 0.4),
+             with_scribbles=False, with_polygons=False, with_segs=False, samplers=True, S=5, mis=0.4, n_inst=2,
+             seg_size=512):
+    print(f"[golden] {tag}: {cfg_name} variant={variant} latent={latent}", flush=True)
+    cfg = load_cfg(cfg_name, variant)
+    model, gi, diffusion, schema, synth = build(cfg)
+    from ldm.models.diffusion.plms import PLMSSampler
+    from ldm.models.diffusion.plms_instance import PLMSSamplerInst
+    g = torch.Generator().manual_seed(1234)
+    bx = torch.tensor(synth.C1_BOXES) if boxes == "c1" else synth.random_boxes(n_boxes, g)
+    gb = synth.make_grounding_batch(batch, bx, g, with_scribbles=with_scribbles, with_polygons=with_polygons,
+                                    with_segs=with_segs, seg_size=seg_size)
+    x = torch.randn(batch, 4, latent, latent, generator=g)
+    context = torch.randn(batch, 77, 768, generator=g)
+    uc = torch.randn(batch, 77, 768, generator=g)
+    t = torch.full((batch,), 981, dtype=torch.long)
+    grounding = gi.prepare(gb)
+    out = {"meta": dict(tag=tag, cfg=cfg_name, variant=variant, alpha_type=list(alpha_type), latent=latent, n_boxes=int(bx.shape[0]), batch=batch,
+                        boxes=boxes, with_scribbles=with_scribbles, with_polygons=with_polygons,
+                        with_segs=with_segs, S=S, mis=mis, n_inst=n_inst, seg_size=seg_size,
+                        x_fp=fp(x), ctx_fp=fp(context))}
+    # --- single forwards, with probes via hooks
+    probes = {}
+    hooks = []
+    for i, blk in enumerate(model.input_blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: probes.__setitem__(f"input_blocks.{i}", fp(o))))
+    hooks.append(model.middle_block.register_forward_hook(lambda m, a, o: probes.__setitem__("middle_block", fp(o))))
+    for i, blk in enumerate(model.output_blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: probes.__setitem__(f"output_blocks.{i}", fp(o))))
+    objs_box = {}
+    hooks.append(model.position_net.register_forward_hook(lambda m, a, o: objs_box.__setitem__("objs", o[0])))
+    eps = model(dict(x=x, timesteps=t, context=context, grounding_input=grounding))
+    out["eps_cond"] = eps.clone()
+    out["probes_cond"] = dict(probes)
+    objs = objs_box["objs"]
+    out["objs_fp"] = fp(objs)
+    out["objs_rows"] = objs[0, [0, 1, 29, 30, 59, 60, 90, 120, 183]].clone()   # one row per token family
+    for h in hooks:
+        h.remove()
+    out["eps_uncond"] = model(dict(x=x, timesteps=t, context=uc)).clone()       # null grounding path
+    ref_set_alpha_scale(model, 0.3)
+    out["eps_scale03"] = model(dict(x=x, timesteps=t, context=context, grounding_input=grounding)).clone()
+    ref_set_alpha_scale(model, 1)
+
+    if samplers:
+        alpha_type = list(alpha_type)
+        first_sd = synth.synth_first_conv_sd()
+        # PLMS + CFG
+        m2 = deepcopy(model)
+        m2.grounding_tokenizer_input = gi
+        patch_first_conv(m2, first_sd)
+        sampler = PLMSSampler(diffusion, m2, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type),
+                              set_alpha_scale=ref_set_alpha_scale)
+        inp = dict(x=x.clone(), timesteps=None, context=context, grounding_input=grounding)
+        out["plms"] = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5).clone()
+        out["plms_timesteps"] = [int(v) for v in sampler.ddim_timesteps]
+        # MIS
+        m3 = deepcopy(model)
+        m3.grounding_tokenizer_input = gi
+        sampler = PLMSSamplerInst(diffusion, m3, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type),
+                                  set_alpha_scale=ref_set_alpha_scale, mis=mis)
+        inputs = [dict(x=x.clone(), timesteps=None, context=context, grounding_input=grounding)]
+        for i in range(n_inst):
+            ctx_i = torch.randn(batch, 77, 768, generator=g)
+            inputs.append(dict(x=x.clone(), timesteps=None, context=ctx_i,
+                               grounding_input=gi.prepare(synth.instance_batch(gb, i))))
+        out["mis"] = sampler.sample(S=S, shape=tuple(x.shape), input=inputs, uc=uc, guidance_scale=7.5).clone()
+        os.chdir(REF)
+    torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
+    return schema
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    args = ap.parse_args()
+    install_shims()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    if args.only in ("all", "tiny"):
+        # tiny: the first-conv swap hard-codes 320 channels (openaimodel.py:478) -> alpha never reaches 0 here
+        gen_case("tiny_box", "test_box.yaml", "tiny", 16, 3, 2, alpha_type=(1, 0, 0))
+        gen_case("tiny_mask", "test_mask.yaml", "tiny", 16, 3, 1, with_polygons=True, with_segs=True, S=4, mis=0.5,
+                 n_inst=1, alpha_type=(1, 0, 0))
+        gen_case("tiny_point", "test_point.yaml", "tiny", 16, 3, 1, samplers=False)
+        gen_case("tiny_scribble", "test_scribble.yaml", "tiny", 16, 3, 1, with_scribbles=True, with_polygons=True,
+                 with_segs=True, samplers=False)
+    if args.only in ("all", "mid"):
+        gen_case("mid_box", "test_box.yaml", "mid", 16, 3, 2)
+    if args.only in ("all", "full"):
+        schema = gen_case("full_box_c1", "test_box.yaml", "full", 64, 4, 1, boxes="c1", samplers=False)
+        json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "unet_schema.json"), "w"))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Shared test-case construction: regenerates exactly the inputs ``oracle/make_golden.py`` fed the reference."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict
+
+import torch
+
+from instancediffusion_amd import synth
+from oracle import ref_cpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, "tests", "golden")
+
+# mirrors oracle/make_golden.py:VARIANTS
+VARIANTS = {
+    "full": dict(),
+    "tiny": dict(model_channels=64, mid_dim=256),
+    "mid": dict(channel_mult=(1, 2, 4), num_res_blocks=1, mid_dim=512),
+}
+DROPS = {
+    "test_box.yaml": dict(test_drop_boxes=False, test_drop_points=False, test_drop_scribbles=True, test_drop_masks=True),
+    "test_mask.yaml": dict(test_drop_boxes=False, test_drop_points=False, test_drop_scribbles=True, test_drop_masks=False),
+    "test_point.yaml": dict(test_drop_boxes=True, test_drop_points=False, test_drop_scribbles=True, test_drop_masks=True),
+    "test_scribble.yaml": dict(test_drop_boxes=False, test_drop_points=False, test_drop_scribbles=False, test_drop_masks=False),
+}
+
+
+def cfg_for(cfg_name: str, variant: str) -> dict:
+    cfg = dict(ref_cpu.DEFAULT_CFG)
+    cfg.update(DROPS[cfg_name])
+    cfg.update(VARIANTS[variant])
+    return cfg
+
+
+def load_golden(tag: str) -> dict:
+    return torch.load(os.path.join(GOLD, f"{tag}.pt"), weights_only=False)
+
+
+def build_inputs(meta: dict) -> Dict[str, torch.Tensor]:
+    """Re-create (x, context, uc, grounding batch, per-instance contexts) exactly as make_golden.gen_case did."""
+    g = torch.Generator().manual_seed(1234)
+    bx = torch.tensor(synth.C1_BOXES) if meta["boxes"] == "c1" else synth.random_boxes(meta["n_boxes"], g)
+    gb = synth.make_grounding_batch(meta["batch"], bx, g, with_scribbles=meta["with_scribbles"],
+                                    with_polygons=meta["with_polygons"], with_segs=meta["with_segs"],
+                                    seg_size=meta["seg_size"])
+    L = meta["latent"]
+    x = torch.randn(meta["batch"], 4, L, L, generator=g)
+    context = torch.randn(meta["batch"], 77, 768, generator=g)
+    uc = torch.randn(meta["batch"], 77, 768, generator=g)
+    inst_ctx = [torch.randn(meta["batch"], 77, 768, generator=g) for _ in range(meta["n_inst"])]
+    return dict(x=x, context=context, uc=uc, gb=gb, inst_ctx=inst_ctx,
+                t=torch.full((meta["batch"],), 981, dtype=torch.long))
+
+
+def unet_schema(cfg: dict) -> Dict[str, tuple]:
+    """State-dict schema {key: shape} of the reference UNet for ``cfg`` -- derived from the HOST mirror classes
+    (whose key set is itself pinned against the reference's in tests/test_schema.py)."""
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from instancediffusion_amd.host.config import unet_kwargs_from_cfg
+    with torch.device("meta"):
+        m = UNetModel(**unet_kwargs_from_cfg(cfg))
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def rel_rms(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.double(); b = b.double()
+    return float(((a - b).pow(2).mean() / b.pow(2).mean().clamp_min(1e-30)).sqrt())

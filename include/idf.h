@@ -1,0 +1,147 @@
+/* idf.h -- C ABI of libidf_gfx950.so: hand-written HIP/CDNA4 kernels for the InstanceDiffusion sampling path.
+ *
+ * The reference (frank-xwang/InstanceDiffusion) is pure Python and has NO FFI: every arithmetic op on its hot
+ * path is a PyTorch ATen call.  Each entry point below REPLACES one family of those ATen call sites; the
+ * reference file:line it replaces is cited per function (paths relative to the reference repo root).
+ * A reference maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless named h_*; no function allocates, frees or synchronises;
+ *   - every launcher enqueues on `stream` (a hipStream_t passed as void*) and is hipGraph-capturable;
+ *   - return: 0 ok; <0 invalid argument (IDF_E_*); >0 a hipError_t from the launch;
+ *   - activations are NHWC / token-major row-major matrices in 16-bit storage (dtype enum below), fp32 accumulate;
+ *   - "ld*" are leading dimensions in ELEMENTS; 16-byte alignment of every row start is required.
+ */
+#ifndef IDF_H_
+#define IDF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDF_ABI_VERSION 1
+
+enum { IDF_BF16 = 0, IDF_F16 = 1 };                 /* 16-bit storage / MFMA input type */
+enum { IDF_E_ARG = -1, IDF_E_ALIGN = -2, IDF_E_UNSUPPORTED = -3 };
+
+/* epilogue flags for idf_gemm / idf_conv3x3 (bitmask) */
+enum {
+  IDF_EPI_BIAS     = 1,    /* + bias[n]                       (f32 [N])                                   */
+  IDF_EPI_ROWBIAS  = 2,    /* + rowbias[m / rows_per_batch][n] (16-bit [*, ld_rowbias])  -- time-embedding */
+  IDF_EPI_RES      = 4,    /* + res[m][n]                     (16-bit, ldr)                                */
+  IDF_EPI_GATE     = 8,    /* out = res + gate[0] * (acc + bias)   (gate: f32 device scalar); needs RES    */
+  IDF_EPI_SILU     = 16,   /* out = silu(acc + bias)                                                       */
+  IDF_EPI_GELU     = 32,   /* out = gelu_erf(acc + bias)                                                   */
+  IDF_EPI_GEGLU    = 64,   /* weight rows interleaved [32 value | 32 gate] per 64; out[m][j] = v * gelu(g) */
+  IDF_EPI_OUT_F32  = 128,  /* store fp32 instead of 16-bit                                                 */
+  IDF_EPI_OUT_NCHW = 256   /* conv only: store fp32 NCHW [B, n_valid, Ho, Wo] (final out conv)             */
+};
+
+int idf_abi_version(void);
+const char* idf_build_info(void);
+
+/* ---- GEMM: out[M,N] = epi( A[M,K] . W[N,K]^T ) ----------------------------------------------------------
+ * Replaces F.linear / 1x1 nn.Conv2d call sites: attention.py:39,59,106-110,168-172,289,349-364;
+ * openaimodel.py:199-205,222,360-364; text_grounding_net.py:73-81,293-298.
+ * Batched over `batch` with element strides (0 = shared).  K % 64 == 0.  With GEGLU, N counts packed W rows
+ * (= 2x output columns).                                                                                    */
+typedef struct {
+  const void* A; const void* W; void* out;
+  const float* bias; const void* rowbias; const void* res; const float* gate;
+  int M, N, K;
+  int lda, ldw, ldo, ldr, ld_rowbias;
+  int rows_per_batch;                 /* ROWBIAS: rowbias row = m / rows_per_batch                          */
+  int batch; long long strideA, strideW, strideO, strideR;
+  int epi; int dtype;
+} idf_gemm_args;
+int idf_gemm(const idf_gemm_args* a, void* stream);
+
+/* ---- 3x3 convolution, pad 1, NHWC, implicit GEMM ---------------------------------------------------------
+ * Replaces nn.Conv2d(k=3) call sites openaimodel.py:185,211 (ResBlock), :132-134 (Downsample, stride 2),
+ * :98,107 (Upsample: nearest x2 folded into the gather), :463 (out conv).  W is [Cout][(ky*3+kx)*Cin + ci].
+ * Cin % 64 == 0.  Output pixel rows m = (b, yo, xo).                                                        */
+typedef struct {
+  const void* x; const void* W; void* out;
+  const float* bias; const void* rowbias; const void* res;
+  int B, Hin, Win, Cin, Cout;
+  int stride;       /* 1 or 2 */
+  int upsample;     /* 0 or 1: input is nearest-upsampled x2 before the conv */
+  int ldx, ldo, ldr, ld_rowbias;
+  int n_valid;      /* OUT_NCHW: number of real output channels (<= Cout) */
+  int epi; int dtype;
+} idf_conv3x3_args;
+int idf_conv3x3(const idf_conv3x3_args* a, void* stream);
+
+/* first conv 4->C directly from the fp32 NCHW latent (openaimodel.py:371, :469-480): out NHWC 16-bit */
+int idf_conv_in(const float* x_nchw, const float* w /*[C][Cin][3][3]*/, const float* bias, void* out,
+                int B, int Cin, int H, int W, int Cout, int dtype, void* stream);
+
+/* ---- fused multi-head attention (flash-style, online softmax) --------------------------------------------
+ * Replaces F.scaled_dot_product_attention call sites attention.py:140,143 (cross), :263,266 (self / gated-self).
+ * out[b][q][h*d + :] = softmax_j(Q.K_j / sqrt(d)) . V_j over TWO key/value segments (segment 1 may be empty):
+ * the gated self-attention concatenates visual tokens and the 184 grounding tokens (attention.py:307) -- the
+ * two-segment form never materialises the concatenation and only computes the N_visual query rows that
+ * attention.py:308 keeps.  V is supplied TRANSPOSED: vt[b][h*d + e][j] (ld = ldv, padded to a multiple of 64).
+ * d % 8 == 0, d <= 160.                                                                                      */
+typedef struct {
+  const void* q; int ldq; long long strideQ; int nq;
+  const void* k0; int ldk0; long long strideK0; const void* vt0; int ldv0; long long strideV0; int n0;
+  const void* k1; int ldk1; long long strideK1; const void* vt1; int ldv1; long long strideV1; int n1;
+  void* out; int ldo; long long strideO;
+  int B, H, d;
+  float scale;      /* d^-0.5 */
+  int dtype;
+} idf_attn_args;
+int idf_attention(const idf_attn_args* a, void* stream);
+
+/* ---- GroupNorm(32 groups) (+SiLU), fp32 statistics (util.py:223-226; attention.py:75-76) -----------------
+ * x/out: [B, HW, C] 16-bit.  ws: f32 workspace of idf_groupnorm_ws_floats(B, HW) floats.                    */
+long long idf_groupnorm_ws_floats(int B, int HW);
+int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
+                  int B, int HW, int C, float eps, int silu, int dtype, void* stream);
+
+/* ---- LayerNorm over the last dim (attention.py:294-295,320-322), eps 1e-5 -------------------------------- */
+int idf_layernorm(const void* x, int ldx, void* out, int ldo, const float* gamma, const float* beta,
+                  int M, int C, float eps, int dtype, void* stream);
+
+/* ---- ScaleU (openaimodel.py:519-539 + Fourier_filter :25-48) ---------------------------------------------
+ * out[b,p,0:Ch] = h * hscale[c];  out[b,p,Ch:Ch+Cs] = skip + sm1[0] * lowfreq4(skip)   (exact 4-bin identity)
+ * hscale = tanh(scaleu_b)+1 (f32 [Ch]); sm1 = tanh(scaleu_s) (f32 scalar on device).
+ * ws: f32 workspace of B*Cs*8 floats.                                                                        */
+int idf_scaleu_concat(const void* h, const void* skip, void* out, const float* hscale, const float* sm1,
+                      float* ws, int B, int H, int W, int Ch, int Cs, int dtype, void* stream);
+
+/* ---- timestep embedding (util.py:160-180): out[b] = [cos(t f_k) | sin(t f_k)], k < dim/2 ----------------- */
+int idf_timestep_embedding(const float* t, void* out, int B, int dim, int dtype, void* stream);
+
+/* ---- UniFusion token-MLP input builder (text_grounding_net.py:216-287; util.py:12-26) --------------------
+ * out[r][0:768]       = tmask[r] ? text[r] : null_text
+ * out[r][768:768+32D] = lmask[r] ? fourier16(loc[r]) : null_loc       (sin/cos interleaved per frequency)   */
+int idf_unifusion_embed(const float* text, const float* loc, const float* tmask, const float* lmask,
+                        const float* null_text, const float* null_loc, const float* freqs /*[16]*/, void* out,
+                        int rows, int text_dim, int D, int dtype, void* stream);
+
+/* ---- samplers: fused CFG + PLMS update (plms.py:121-165) -------------------------------------------------
+ * eps buffers hold [cond | uncond] stacked on batch (2n floats-per-half n).  Writes e_t (guided eps) and, if
+ * x_out != NULL, x_prev for the Adams-Bashforth order given by n_old (0 -> plain e_t: first-step predictor).   */
+int idf_cfg_combine(const float* eps_cond, const float* eps_uncond, float guidance, float* e_t,
+                    long long n, void* stream);
+int idf_plms_update(const float* x, const float* e_t, const float* e1, const float* e2, const float* e3,
+                    const float* e_next, int mode, float a_t, float a_prev, float sqrt_1m_at,
+                    float* x_out, long long n, void* stream);
+
+/* ---- Multi-instance Sampler merge (plms_instance.py:112-135) ---------------------------------------------
+ * lat: [n_inst+1][B][C][H][W] fp32.  mode 0: mean over the first dim; mode 1: crop-and-paste of instance j's
+ * latent box (boxes: int32 [n_inst][4] = int(box*latent_size), reference index order dim2<-x, dim3<-y).      */
+int idf_mis_merge(const float* lat, const int* boxes, float* out, int n_inst, int B, int C, int H, int W,
+                  int mode, void* stream);
+
+/* ---- layout helpers ---------------------------------------------------------------------------------------*/
+int idf_cast_f32_to_16(const float* x, void* out, long long n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDF_H_ */

@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI declared in ``include/idf.h`` (``libidf_gfx950.so``).
+
+Fails LOUDLY if the shared library is missing: there is no CPU / eager fallback in the product path.
+Build with ``instancediffusion_amd/csrc/build.sh`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidf_gfx950.so")
+
+IDF_BF16, IDF_F16 = 0, 1
+EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256
+
+vp, ll, ci, cf = C.c_void_p, C.c_longlong, C.c_int, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("W", vp), ("out", vp), ("bias", vp), ("rowbias", vp), ("res", vp), ("gate", vp),
+                ("M", ci), ("N", ci), ("K", ci),
+                ("lda", ci), ("ldw", ci), ("ldo", ci), ("ldr", ci), ("ld_rowbias", ci),
+                ("rows_per_batch", ci),
+                ("batch", ci), ("strideA", ll), ("strideW", ll), ("strideO", ll), ("strideR", ll),
+                ("epi", ci), ("dtype", ci)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", vp), ("W", vp), ("out", vp), ("bias", vp), ("rowbias", vp), ("res", vp),
+                ("B", ci), ("Hin", ci), ("Win", ci), ("Cin", ci), ("Cout", ci),
+                ("stride", ci), ("upsample", ci),
+                ("ldx", ci), ("ldo", ci), ("ldr", ci), ("ld_rowbias", ci),
+                ("n_valid", ci), ("epi", ci), ("dtype", ci)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("ldq", ci), ("strideQ", ll), ("nq", ci),
+                ("k0", vp), ("ldk0", ci), ("strideK0", ll), ("vt0", vp), ("ldv0", ci), ("strideV0", ll), ("n0", ci),
+                ("k1", vp), ("ldk1", ci), ("strideK1", ll), ("vt1", vp), ("ldv1", ci), ("strideV1", ll), ("n1", ci),
+                ("out", vp), ("ldo", ci), ("strideO", ll),
+                ("B", ci), ("H", ci), ("d", ci), ("scale", cf), ("dtype", ci)]
+
+
+# every symbol include/idf.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "idf_abi_version": (ci, []),
+    "idf_build_info": (C.c_char_p, []),
+    "idf_gemm": (ci, [C.POINTER(GemmArgs), vp]),
+    "idf_conv3x3": (ci, [C.POINTER(ConvArgs), vp]),
+    "idf_conv_in": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "idf_attention": (ci, [C.POINTER(AttnArgs), vp]),
+    "idf_groupnorm_ws_floats": (ll, [ci, ci]),
+    "idf_groupnorm": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]),
+    "idf_layernorm": (ci, [vp, ci, vp, ci, vp, vp, ci, ci, cf, ci, vp]),
+    "idf_scaleu_concat": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "idf_timestep_embedding": (ci, [vp, vp, ci, ci, ci, vp]),
+    "idf_unifusion_embed": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "idf_cfg_combine": (ci, [vp, vp, cf, vp, ll, vp]),
+    "idf_plms_update": (ci, [vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, vp, ll, vp]),
+    "idf_mis_merge": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "idf_cast_f32_to_16": (ci, [vp, vp, ll, ci, vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
+            f"(run instancediffusion_amd/csrc/build.sh or __graft_entry__.build()). "
+            f"There is no CPU fallback for the InstanceDiffusion sampling path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.idf_abi_version() != 1:
+        raise RuntimeError("libidf_gfx950.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class IdfError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str):
+    if status != 0:
+        kind = {-1: "invalid argument", -2: "misaligned pointer/leading dimension", -3: "unsupported"}.get(
+            status, f"hipError_t {status}")
+        raise IdfError(f"{what} failed: {kind}")

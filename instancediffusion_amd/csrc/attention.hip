@@ -1,0 +1,278 @@
+// attention.hip -- fused multi-head attention forward for gfx950 (flash-style online softmax), head dims 8..160.
+//
+// One workgroup = 4 wave64 = 128 query rows of one (batch, head); each wave owns 32 query rows.  Per KV tile of 64:
+//   S^T[kv][q] = K . Q^T     v_mfma_f32_32x32x16 with A = K tile (LDS, ds_read_b128), B = Q fragment (registers)
+//   "swapped" product: each lane owns ONE query column (q = lane&31) and 2x16 kv rows, so the softmax row
+//   reductions are lane-local + one cross-half exchange (lane ^ 32); P never touches LDS.
+//   O^T[e][q] += V^T . P^T   A = V^T tile (LDS, 2x ds_read_b64 per fragment), B = P packed to 16-bit in registers.
+//   The k-ordering of the packed P fragment and of the V^T fragment is the same self-chosen permutation
+//   (kv = 16*step + 4*hi + {0..3} and +8), so no lane shuffles are needed.
+// K/V of the NEXT tile are prefetched global->registers while the MFMAs of the current tile run.
+// Two KV segments (visual tokens + grounding tokens) implement the gated self-attention without materialising
+// the concatenation (reference attention.py:307).
+//
+// Roofline: MFMA-bound; algorithmic flops = 4 * nq * (n0+n1) * d per (b, h).
+#include "common.h"
+
+namespace {
+
+constexpr int KVT = 64;            // kv rows per tile
+constexpr int VSTR = 68;           // V^T LDS row stride in elements (136 B: odd number of 8-B slots)
+
+struct AttnParams {
+  const unsigned short* q; int ldq; long long sQ; int nq;
+  const unsigned short* k[2]; int ldk[2]; long long sK[2];
+  const unsigned short* vt[2]; int ldv[2]; long long sV[2]; int n[2];
+  unsigned short* out; int ldo; long long sO;
+  int H, d;
+  float scale_log2;   // d^-0.5 * log2(e)
+};
+
+// NKS = ceil(d/16) K-steps of the QK^T contraction, NMT = ceil(d/32) 32-row tiles of O^T.
+template <int DT, int NKS, int NMT>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+  constexpr int KSTR = (2 * NKS + 1) * 8;          // K LDS row stride (elements): odd number of 16-B slots
+  constexpr int KCH_MAX = (KVT * 2 * NKS + 255) / 256;
+  constexpr int VCH_MAX = (NMT * 32 * 8 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned short Kl[KVT * KSTR];
+  __shared__ __attribute__((aligned(16))) unsigned short Vl[NMT * 32 * VSTR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = p.d;
+  const int dch = d >> 3;                            // 16-B chunks per K row
+  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+
+  // zero LDS once: pad columns of K (d..16*NKS) and pad rows of V^T (d..32*NMT) must stay finite zeros
+  for (int i = tid; i < KVT * KSTR / 2; i += 256) reinterpret_cast<unsigned*>(Kl)[i] = 0u;
+  for (int i = tid; i < NMT * 32 * VSTR / 2; i += 256) reinterpret_cast<unsigned*>(Vl)[i] = 0u;
+
+  // ---- Q fragments (B operand): lane holds q = l31, e = 16*ks + 8*hi .. +7
+  u32x4 qf[NKS];
+  {
+    const int qr = min(qrow, p.nq - 1);
+    const unsigned short* qp = p.q + (size_t)b * p.sQ + (size_t)qr * p.ldq + h * d;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int e0 = ks * 16 + hi * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (e0 < d) v = *reinterpret_cast<const u32x4*>(qp + e0);
+      qf[ks] = v;
+    }
+  }
+
+  const int T0 = (p.n[0] + KVT - 1) / KVT;
+  const int T1 = (p.n[1] + KVT - 1) / KVT;
+  const int T = T0 + T1;
+
+  // ---- staging registers (prefetch of the next tile)
+  u32x4 kreg[KCH_MAX], vreg[VCH_MAX];
+  auto prefetch = [&](int t) {
+    const int seg = (t < T0) ? 0 : 1;
+    const int kv0 = (seg ? (t - T0) : t) * KVT;
+    const int n = p.n[seg];
+    const unsigned short* kb = p.k[seg] + (size_t)b * p.sK[seg] + h * d;
+    const unsigned short* vb = p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * d) * p.ldv[seg] + kv0;
+#pragma unroll
+    for (int i = 0; i < KCH_MAX; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / dch, ch = id - row * dch;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < KVT) {
+        const int kr = min(kv0 + row, n - 1);
+        v = *reinterpret_cast<const u32x4*>(kb + (size_t)kr * p.ldk[seg] + ch * 8);
+      }
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH_MAX; ++i) {
+      const int id = tid + i * 256;
+      const int row = id >> 3, ch = id & 7;       // row = e (0..d-1), 8 chunks of 8 kv
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < d) {
+        v = *reinterpret_cast<const u32x4*>(vb + (size_t)row * p.ldv[seg] + ch * 8);
+        const int valid = n - (kv0 + ch * 8);      // number of valid kv in this chunk (may be <=0 or >=8)
+        if (valid < 8) {                           // zero the invalid tail (keeps 0 * garbage out of P.V)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            unsigned m = 0xffffffffu;
+            if (valid <= 2 * w) m = 0u; else if (valid == 2 * w + 1) m = 0x0000ffffu;
+            v[w] &= m;
+          }
+        }
+      }
+      vreg[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KCH_MAX; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / dch, ch = id - row * dch;
+      if (row < KVT) *reinterpret_cast<u32x4*>(Kl + row * KSTR + ch * 8) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VCH_MAX; ++i) {
+      const int id = tid + i * 256;
+      const int row = id >> 3, ch = id & 7;
+      if (row < d) {
+        // VSTR*2 = 136 B is only 8-B aligned: two 8-B stores
+        u32x2 lo = {vreg[i][0], vreg[i][1]}, hi2 = {vreg[i][2], vreg[i][3]};
+        *reinterpret_cast<u32x2*>(Vl + row * VSTR + ch * 8) = lo;
+        *reinterpret_cast<u32x2*>(Vl + row * VSTR + ch * 8 + 4) = hi2;
+      }
+    }
+  };
+
+  f32x16 o[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[mt][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  const float c = p.scale_log2;
+
+  prefetch(0);
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();            // every wave finished reading the previous tile (and the zero-fill, t == 0)
+    commit();
+    __syncthreads();
+    if (t + 1 < T) prefetch(t + 1);
+
+    const int seg = (t < T0) ? 0 : 1;
+    const int kv0 = (seg ? (t - T0) : t) * KVT;
+    const int nvalid = p.n[seg] - kv0;            // >= 1
+
+    // ---- S^T = K Q^T  (2 tiles of 32 kv rows)
+    f32x16 s[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[st][r] = 0.0f;
+      const unsigned short* kf = Kl + (st * 32 + l31) * KSTR + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        u32x4 a = *reinterpret_cast<const u32x4*>(kf + ks * 16);
+        s[st] = Elem<DT>::mfma32(a, qf[ks], s[st]);
+      }
+    }
+    // ---- mask the tail, running max.  s[st][r]: kv = kv0 + st*32 + (r&3) + 8*(r>>2) + 4*hi
+    if (nvalid < KVT) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv >= nvalid) s[st][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * c);      // c > 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+    m_run = m_new;
+    float rs = 0.0f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[st][r], c, -m_new));
+        s[st][r] = pv;
+        rs += pv;
+      }
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+
+    // ---- O^T += V^T P^T.  K-step (st, k2): P regs 8*k2..8*k2+7 of tile st  <->  kv = st*32 + 16*k2 + 4*hi + {0..3, 8..11}
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        u32x4 pf;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pf[w] = pack2<DT>(s[st][8 * k2 + 2 * w], s[st][8 * k2 + 2 * w + 1]);
+        const int kvoff = st * 32 + 16 * k2 + 4 * hi;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          const unsigned short* vf = Vl + (mt * 32 + l31) * VSTR + kvoff;
+          u32x2 v0 = *reinterpret_cast<const u32x2*>(vf);
+          u32x2 v1 = *reinterpret_cast<const u32x2*>(vf + 8);
+          u32x4 a = {v0[0], v0[1], v1[0], v1[1]};
+          o[mt] = Elem<DT>::mfma32(a, pf, o[mt]);
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store.  o[mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < p.nq) {
+    unsigned short* op = p.out + (size_t)b * p.sO + (size_t)qrow * p.ldo + h * d;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int e = mt * 32 + 8 * qd + 4 * hi;
+        if (e < d) {   // d % 8 == 0 and e % 4 == 0 -> the 4 columns are all valid
+          u32x2 pk = {pack2<DT>(o[mt][4 * qd] * inv, o[mt][4 * qd + 1] * inv),
+                      pack2<DT>(o[mt][4 * qd + 2] * inv, o[mt][4 * qd + 3] * inv)};
+          *reinterpret_cast<u32x2*>(op + e) = pk;
+        }
+      }
+  }
+}
+
+template <int DT>
+int launch_attn(const AttnParams& p, int B, hipStream_t s) {
+  dim3 grid((p.nq + 127) / 128, p.H, B), block(256);
+  const int nks = (p.d + 15) / 16, nmt = (p.d + 31) / 32;
+#define IDF_ATTN_CASE(KS, MT) \
+  if (nks == KS && nmt == MT) { hipLaunchKernelGGL((attn_kernel<DT, KS, MT>), grid, block, 0, s, p); return idf_launch_status(); }
+  IDF_ATTN_CASE(1, 1)    // d = 8, 16
+  IDF_ATTN_CASE(2, 1)    // d = 24, 32
+  IDF_ATTN_CASE(3, 2)    // d = 40, 48
+  IDF_ATTN_CASE(4, 2)    // d = 56, 64
+  IDF_ATTN_CASE(5, 3)    // d = 72, 80
+  IDF_ATTN_CASE(6, 3)    // d = 88, 96
+  IDF_ATTN_CASE(8, 4)    // d = 120, 128
+  IDF_ATTN_CASE(10, 5)   // d = 152, 160
+#undef IDF_ATTN_CASE
+  return IDF_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
+  if (!a || !a->q || !a->k0 || !a->vt0 || !a->out) return IDF_E_ARG;
+  if (a->B <= 0 || a->H <= 0 || a->d <= 0 || (a->d % 8) || a->d > 160 || a->nq <= 0 || a->n0 <= 0 || a->n1 < 0) return IDF_E_ARG;
+  if (a->n1 > 0 && (!a->k1 || !a->vt1)) return IDF_E_ARG;
+  if ((a->ldq % 8) || (a->ldk0 % 8) || (a->ldv0 % 8) || (a->ldo % 4)) return IDF_E_ALIGN;
+  if (a->n1 > 0 && ((a->ldk1 % 8) || (a->ldv1 % 8))) return IDF_E_ALIGN;
+  // every KV tile reads 64 columns of V^T: the row length must cover the rounded-up segment
+  if (a->ldv0 < ((a->n0 + 63) / 64) * 64) return IDF_E_ARG;
+  if (a->n1 > 0 && a->ldv1 < ((a->n1 + 63) / 64) * 64) return IDF_E_ARG;
+  if (!aligned16(a->q) || !aligned16(a->k0) || !aligned16(a->vt0)) return IDF_E_ALIGN;
+  AttnParams p{};
+  p.q = (const unsigned short*)a->q; p.ldq = a->ldq; p.sQ = a->strideQ; p.nq = a->nq;
+  p.k[0] = (const unsigned short*)a->k0; p.ldk[0] = a->ldk0; p.sK[0] = a->strideK0;
+  p.vt[0] = (const unsigned short*)a->vt0; p.ldv[0] = a->ldv0; p.sV[0] = a->strideV0; p.n[0] = a->n0;
+  p.k[1] = (const unsigned short*)(a->n1 > 0 ? a->k1 : a->k0); p.ldk[1] = a->n1 > 0 ? a->ldk1 : a->ldk0; p.sK[1] = a->strideK1;
+  p.vt[1] = (const unsigned short*)(a->n1 > 0 ? a->vt1 : a->vt0); p.ldv[1] = a->n1 > 0 ? a->ldv1 : a->ldv0; p.sV[1] = a->strideV1;
+  p.n[1] = a->n1;
+  p.out = (unsigned short*)a->out; p.ldo = a->ldo; p.sO = a->strideO;
+  p.H = a->H; p.d = a->d;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == IDF_BF16) return launch_attn<IDF_BF16>(p, a->B, s);
+  if (a->dtype == IDF_F16) return launch_attn<IDF_F16>(p, a->B, s);
+  return IDF_E_UNSUPPORTED;
+}

@@ -1,0 +1,76 @@
+// common.h -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.  Written for MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/idf.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// ---- 16-bit storage <-> f32 ------------------------------------------------------------------------------
+template <int DT> struct Elem;   // DT = IDF_BF16 / IDF_F16
+
+template <> struct Elem<IDF_BF16> {
+  static __device__ __forceinline__ float to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) {   // round-to-nearest-even
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <> struct Elem<IDF_F16> {
+  static __device__ __forceinline__ float to_f32(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+  static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <int DT> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)Elem<DT>::from_f32(lo) | ((unsigned)Elem<DT>::from_f32(hi) << 16);
+}
+template <int DT> __device__ __forceinline__ void unpack8(u32x4 v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = Elem<DT>::to_f32((unsigned short)(v[i] & 0xffffu));
+    f[2 * i + 1] = Elem<DT>::to_f32((unsigned short)(v[i] >> 16));
+  }
+}
+template <int DT> __device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2<DT>(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// wave64 butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int idf_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,313 @@
+// gemm_conv.hip -- MFMA GEMM core for gfx950 shared by idf_gemm (linear / 1x1 conv) and idf_conv3x3 (implicit
+// GEMM with an on-the-fly NHWC im2col gather, optional stride 2 and folded nearest-x2 upsample).
+//
+// Design (MI355X): 256-thread workgroup = 4 wave64; v_mfma_f32_32x32x16_{bf16,f16}; block tile BM x BN x 64,
+// double-buffered LDS (row stride 144 B = odd number of 16-B slots -> conflict-free ds_read_b128 fragment reads),
+// register-staged global->LDS with the next tile's loads in flight during the MFMAs, ONE barrier per K-tile.
+// The MFMA "A" operand is the WEIGHT tile and "B" the activation tile, so every lane ends up owning 4 consecutive
+// output columns of one output row: epilogue = 8-byte packed stores, float4 bias loads, in-register GEGLU.
+//
+// Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops = 2*M*N*K.
+#include "common.h"
+
+namespace {
+
+struct CoreParams {
+  const unsigned short* W; int ldw; long long strideW; int N;
+  const unsigned short* A; int lda; long long strideA; int M; int K;
+  int Hin, Win, Cin, Ho, Wo, stride, up;           // conv gather
+  void* out; int ldo; long long strideO;
+  const float* bias; const unsigned short* rowbias; int ld_rowbias; int rows_per_batch;
+  const unsigned short* res; int ldr; long long strideR;
+  const float* gate; int epi; int n_valid;
+};
+
+constexpr int BK = 64;
+constexpr int LSTR = 72;   // LDS row stride in elements (144 B)
+
+template <int DT, int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int AR = BM / 32, WR = BN / 32;          // rows staged per thread
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  constexpr int BUF = (BM + BN) * LSTR;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int bz = blockIdx.z;
+
+  const unsigned short* Wb = p.W + (size_t)bz * p.strideW;
+  const unsigned short* Ab = p.A + (size_t)bz * p.strideA;
+
+  // ---- staging roles: thread -> (16-B chunk c along k, rows r0 + 32 i)
+  const int c = tid & 7, r0 = tid >> 3;
+  const unsigned short* wrow[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = min(n0 + r0 + 32 * i, p.N - 1);
+    wrow[i] = Wb + (size_t)n * p.ldw + c * 8;
+  }
+  const unsigned short* arow[AR];
+  int ay[AR], ax[AR];                                  // conv: output pixel coords (pre-multiplied by stride, -1)
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = min(m0 + r0 + 32 * i, p.M - 1);
+    if (CONV) {
+      int hw = p.Ho * p.Wo;
+      int b = m / hw, rem = m - b * hw;
+      int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      ay[i] = yo * p.stride - 1;
+      ax[i] = xo * p.stride - 1;
+      arow[i] = Ab + (size_t)b * p.Hin * p.Win * p.lda + c * 8;
+    } else {
+      ay[i] = ax[i] = 0;
+      arow[i] = Ab + (size_t)m * p.lda + c * 8;
+    }
+  }
+  const int nk = p.K / BK;
+  int tap = 0, ci0 = 0;                                // conv: K-tile -> (3x3 tap, channel offset)
+
+  u32x4 ra[AR], rw[WR];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < WR; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt * BK);
+    if (CONV) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int yi = ay[i] + ky, xi = ax[i] + kx;
+        bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
+        int ys = yi >> p.up, xs = xi >> p.up;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(arow[i] + ((size_t)ys * p.Win + xs) * p.lda + ci0);
+        ra[i] = v;
+      }
+      ci0 += BK;
+      if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const u32x4*>(arow[i] + (size_t)kt * BK);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned short* Al = smem + buf * BUF;
+    unsigned short* Wl = Al + BM * LSTR;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4*>(Al + (r0 + 32 * i) * LSTR + c * 8) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) *reinterpret_cast<u32x4*>(Wl + (r0 + 32 * i) * LSTR + c * 8) = rw[i];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) load_tile(kt + 1);
+    const unsigned short* Al = smem + (kt & 1) * BUF;
+    const unsigned short* Wl = Al + BM * LSTR;
+    const unsigned short* af_base = Al + (wm * WM + l31) * LSTR + hi * 8;
+    const unsigned short* wf_base = Wl + (wn * WN + l31) * LSTR + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      u32x4 wf[TN], af[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * LSTR + ks * 16);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * LSTR + ks * 16);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[a], af[b], acc[a][b]);
+    }
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[a][b][r]: n = nb + (r&3) + 8*(r>>2) + 4*hi ; m = mb + l31
+  const int epi = p.epi;
+  const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+  const unsigned short* resb = p.res ? p.res + (size_t)bz * p.strideR : nullptr;
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int m = m0 + wm * WM + b * 32 + l31;
+    if (m >= p.M) continue;
+    const int brow = (epi & IDF_EPI_ROWBIAS) ? (m / p.rows_per_batch) : 0;
+    if (epi & IDF_EPI_GEGLU) {
+      if constexpr (TN >= 2) {
+#pragma unroll
+        for (int a = 0; a < TN; a += 2) {
+          const int nb = n0 + wn * WN + a * 32;         // packed row base (multiple of 64)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int off = 8 * q + 4 * hi;
+            if (nb + 32 + off >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float xv = acc[a][b][4 * q + e] + p.bias[nb + off + e];
+              float gv = acc[a + 1][b][4 * q + e] + p.bias[nb + 32 + off + e];
+              v[e] = xv * gelu_erf_f(gv);
+            }
+            const int j = nb / 2 + off;
+            unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + j;
+            u32x2 pk = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(o) = pk;
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * WN + a * 32 + 8 * q + 4 * hi;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e];
+        const bool full = (n + 3 < p.N);
+        if (epi & IDF_EPI_BIAS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (full || n + e < p.N) v[e] += p.bias[n + e];
+        }
+        if (epi & IDF_EPI_ROWBIAS) {
+          const unsigned short* rb = p.rowbias + (size_t)brow * p.ld_rowbias + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (full || n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
+        }
+        if (epi & IDF_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+        if (epi & IDF_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+        }
+        if (epi & IDF_EPI_RES) {
+          const unsigned short* rr = resb + (size_t)m * p.ldr + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (full || n + e < p.N) {
+              float rv = Elem<DT>::to_f32(rr[e]);
+              v[e] = (epi & IDF_EPI_GATE) ? (rv + gate * v[e]) : (rv + v[e]);
+            }
+          }
+        }
+        if (epi & IDF_EPI_OUT_NCHW) {
+          const int hw = p.Ho * p.Wo;
+          const int bb = m / hw, rem = m - bb * hw;
+          float* o = reinterpret_cast<float*>(p.out);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.n_valid) o[((size_t)bb * p.n_valid + (n + e)) * hw + rem] = v[e];
+        } else if (epi & IDF_EPI_OUT_F32) {
+          float* o = reinterpret_cast<float*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (full || n + e < p.N) o[e] = v[e];
+        } else {
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+          if (full && ((p.ldo & 3) == 0)) {
+            u32x2 pk = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(o) = pk;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int DT, int BM, int BN, int WM, int WN, bool CONV>
+int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
+  auto kern = gemm_kernel<DT, BM, BN, WM, WN, CONV>;
+  constexpr int smem = 2 * (BM + BN) * LSTR * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  return idf_launch_status();
+}
+
+template <int DT, bool CONV>
+int launch(const CoreParams& p, int batch, hipStream_t s) {
+  const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
+  // tile choice: 128x128 when N fills it; 128(M) x 64(N) for N = 64 mod 128 (e.g. 320) or small N
+  if (geglu || (p.N % 128 == 0) || p.N > 1024) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
+  return launch_cfg<DT, 128, 64, 64, 32, CONV>(p, batch, s);
+}
+
+}  // namespace
+
+extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->W || !a->out) return IDF_E_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return IDF_E_ARG;
+  if ((a->lda % 8) || (a->ldw % 8) || !aligned16(a->A) || !aligned16(a->W)) return IDF_E_ALIGN;
+  if ((a->epi & IDF_EPI_GATE) && !(a->epi & IDF_EPI_RES)) return IDF_E_ARG;
+  if ((a->epi & IDF_EPI_RES) && !a->res) return IDF_E_ARG;
+  if ((a->epi & (IDF_EPI_BIAS | IDF_EPI_GEGLU)) && !a->bias) return IDF_E_ARG;
+  if ((a->epi & IDF_EPI_GEGLU) && ((a->N % 64) || (a->ldo % 4))) return IDF_E_ARG;
+  if ((a->epi & IDF_EPI_ROWBIAS) && (!a->rowbias || a->rows_per_batch <= 0)) return IDF_E_ARG;
+  if (a->epi & IDF_EPI_OUT_NCHW) return IDF_E_ARG;
+  CoreParams p{};
+  p.W = (const unsigned short*)a->W; p.ldw = a->ldw; p.strideW = a->strideW; p.N = a->N;
+  p.A = (const unsigned short*)a->A; p.lda = a->lda; p.strideA = a->strideA; p.M = a->M; p.K = a->K;
+  p.out = a->out; p.ldo = a->ldo; p.strideO = a->strideO;
+  p.bias = a->bias; p.rowbias = (const unsigned short*)a->rowbias; p.ld_rowbias = a->ld_rowbias;
+  p.rows_per_batch = a->rows_per_batch;
+  p.res = (const unsigned short*)a->res; p.ldr = a->ldr; p.strideR = a->strideR;
+  p.gate = a->gate; p.epi = a->epi; p.n_valid = a->N;
+  const int batch = a->batch > 0 ? a->batch : 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == IDF_BF16) return launch<IDF_BF16, false>(p, batch, s);
+  if (a->dtype == IDF_F16) return launch<IDF_F16, false>(p, batch, s);
+  return IDF_E_UNSUPPORTED;
+}
+
+extern "C" int idf_conv3x3(const idf_conv3x3_args* a, void* stream) {
+  if (!a || !a->x || !a->W || !a->out) return IDF_E_ARG;
+  if (a->B <= 0 || a->Cin <= 0 || (a->Cin % BK) != 0 || a->Cout <= 0) return IDF_E_ARG;
+  if (a->stride != 1 && a->stride != 2) return IDF_E_ARG;
+  if (a->upsample != 0 && a->upsample != 1) return IDF_E_ARG;
+  if ((a->ldx % 8) || !aligned16(a->x) || !aligned16(a->W)) return IDF_E_ALIGN;
+  if (a->epi & (IDF_EPI_GEGLU | IDF_EPI_GATE)) return IDF_E_ARG;
+  if ((a->epi & IDF_EPI_RES) && !a->res) return IDF_E_ARG;
+  if ((a->epi & IDF_EPI_BIAS) && !a->bias) return IDF_E_ARG;
+  CoreParams p{};
+  const int Hup = a->Hin << a->upsample, Wup = a->Win << a->upsample;
+  p.Ho = (Hup - 1) / a->stride + 1; p.Wo = (Wup - 1) / a->stride + 1;
+  p.W = (const unsigned short*)a->W; p.ldw = 9 * a->Cin; p.strideW = 0; p.N = a->Cout;
+  p.A = (const unsigned short*)a->x; p.lda = a->ldx; p.strideA = 0; p.M = a->B * p.Ho * p.Wo; p.K = 9 * a->Cin;
+  p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin; p.stride = a->stride; p.up = a->upsample;
+  p.out = a->out; p.ldo = a->ldo; p.strideO = 0;
+  p.bias = a->bias; p.rowbias = (const unsigned short*)a->rowbias; p.ld_rowbias = a->ld_rowbias;
+  p.rows_per_batch = p.Ho * p.Wo;
+  p.res = (const unsigned short*)a->res; p.ldr = a->ldr; p.strideR = 0;
+  p.gate = nullptr; p.epi = a->epi; p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout;
+  if ((a->epi & IDF_EPI_ROWBIAS) && !a->rowbias) return IDF_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == IDF_BF16) return launch<IDF_BF16, true>(p, 1, s);
+  if (a->dtype == IDF_F16) return launch<IDF_F16, true>(p, 1, s);
+  return IDF_E_UNSUPPORTED;
+}

@@ -1,0 +1,213 @@
+// misc.hip -- small latency-bound kernels of the sampling path (gfx950): timestep embedding, UniFusion token-MLP
+// input builder, first conv from the fp32 NCHW latent, fused CFG / PLMS update, Multi-instance-Sampler merge.
+#include "common.h"
+
+namespace {
+
+// util.py:160-180: out[b] = [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(10000) k / half)
+template <int DT>
+__global__ void temb_kernel(const float* __restrict__ t, unsigned short* __restrict__ out, int B, int dim) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[b] * f;
+  out[(size_t)b * dim + k] = Elem<DT>::from_f32(cosf(a));
+  out[(size_t)b * dim + half + k] = Elem<DT>::from_f32(sinf(a));
+}
+
+// text_grounding_net.py:216-287 + util.py:12-26.  One thread per output element of [rows, text_dim + 32*D].
+template <int DT>
+__global__ void unifusion_embed_kernel(const float* __restrict__ text, const float* __restrict__ loc,
+                                       const float* __restrict__ tmask, const float* __restrict__ lmask,
+                                       const float* __restrict__ null_text, const float* __restrict__ null_loc,
+                                       const float* __restrict__ freqs,
+                                       unsigned short* __restrict__ out, int rows, int text_dim, int D) {
+  const int width = text_dim + 32 * D;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * width) return;
+  const int r = (int)(i / width), col = (int)(i - (size_t)r * width);
+  float v;
+  if (col < text_dim) {
+    const float m = tmask[r];
+    v = text[(size_t)r * text_dim + col] * m + (1.0f - m) * null_text[col];
+  } else {
+    const int e = col - text_dim;                 // e = (2*j + is_cos) * D + i
+    const int blk = e / D, idx = e - blk * D;
+    const int j = blk >> 1;
+    const float freq = freqs[j];                  // freq_bands = 100 ** (j / 16), host-computed (util.py:17)
+    const float a = freq * loc[(size_t)r * D + idx];
+    const float fe = (blk & 1) ? cosf(a) : sinf(a);
+    const float m = lmask[r];
+    v = fe * m + (1.0f - m) * null_loc[e];
+  }
+  out[i] = Elem<DT>::from_f32(v);
+}
+
+// first conv (Cin = 4): NCHW fp32 latent -> NHWC 16-bit.  One thread per (pixel, 8 output channels).
+template <int DT>
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, unsigned short* __restrict__ out,
+                                                     int B, int Cin, int H, int W, int Cout) {
+  const int cg = Cout >> 3;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * H * W * cg) return;
+  const int g = (int)(i % cg);
+  const size_t pix = i / cg;
+  const int b = (int)(pix / (H * W)), r = (int)(pix - (size_t)b * H * W);
+  const int y = r / W, xx = r - y * W;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xc = xx + kx - 1;
+        if (xc < 0 || xc >= W) continue;
+        const float xv = xp[yy * W + xc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, w[(((size_t)(g * 8 + j) * Cin + ci) * 3 + ky) * 3 + kx], acc[j]);
+      }
+    }
+  }
+  *reinterpret_cast<u32x4*>(out + pix * Cout + g * 8) = pack8<DT>(acc);
+}
+
+__global__ void cfg_kernel(const float* __restrict__ ec, const float* __restrict__ eu, float g, float* __restrict__ et, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float u = eu[i]; et[i] = u + g * (ec[i] - u); }
+}
+
+// plms.py:130-165.  mode 0: e' = e_t; 1: (e_t + e_next)/2; 2: (3 e_t - e1)/2; 3: (23 e_t - 16 e1 + 5 e2)/12;
+// 4: (55 e_t - 59 e1 + 37 e2 - 9 e3)/24.   x_prev = sqrt(a_prev) (x - sqrt(1-a_t) e')/sqrt(a_t) + sqrt(1-a_prev) e'
+__global__ void plms_kernel(const float* __restrict__ x, const float* __restrict__ et, const float* __restrict__ e1,
+                            const float* __restrict__ e2, const float* __restrict__ e3, const float* __restrict__ en,
+                            int mode, float sqrt_at, float sqrt_aprev, float sqrt_1m_at, float sqrt_1m_aprev,
+                            float* __restrict__ xo, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = et[i];
+  float ep;
+  switch (mode) {
+    case 0: ep = e; break;
+    case 1: ep = (e + en[i]) / 2.0f; break;
+    case 2: ep = (3.0f * e - e1[i]) / 2.0f; break;
+    case 3: ep = (23.0f * e - 16.0f * e1[i] + 5.0f * e2[i]) / 12.0f; break;
+    default: ep = (55.0f * e - 59.0f * e1[i] + 37.0f * e2[i] - 9.0f * e3[i]) / 24.0f; break;
+  }
+  const float pred_x0 = (x[i] - sqrt_1m_at * ep) / sqrt_at;
+  xo[i] = sqrt_aprev * pred_x0 + sqrt_1m_aprev * ep;
+}
+
+// plms_instance.py:112-135
+__global__ void mis_merge_kernel(const float* __restrict__ lat, const int* __restrict__ boxes, float* __restrict__ out,
+                                 int n_inst, int B, int C, int H, int W, int mode) {
+  const long long per = (long long)B * C * H * W;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  if (mode == 0) {
+    float s = 0.f;
+    for (int k = 0; k <= n_inst; ++k) s += lat[(long long)k * per + i];
+    out[i] = s / (float)(n_inst + 1);                // torch.mean(torch.stack(...), 0)
+  } else {
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    float v = lat[i];
+    for (int k = 0; k < n_inst; ++k) {               // later instances overwrite earlier ones, as in the loop :131-132
+      const int* bb = boxes + 4 * k;
+      // reference slices dim-2 (h) with bbox[0]:bbox[2] and dim-3 (w) with bbox[1]:bbox[3]
+      if (h >= bb[0] && h < bb[2] && w >= bb[1] && w < bb[3]) v = lat[(long long)(k + 1) * per + i];
+    }
+    out[i] = v;
+  }
+}
+
+template <int DT>
+__global__ void cast_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = Elem<DT>::from_f32(x[i]);
+}
+
+inline dim3 grid1d(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+extern "C" int idf_abi_version(void) { return IDF_ABI_VERSION; }
+extern "C" const char* idf_build_info(void) { return "libidf_gfx950 (hand-written HIP, gfx950 / CDNA4, wave64, MFMA 32x32x16) " __DATE__; }
+
+extern "C" int idf_timestep_embedding(const float* t, void* out, int B, int dim, int dtype, void* stream) {
+  if (!t || !out || B <= 0 || dim <= 0 || (dim & 1)) return IDF_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * (dim / 2);
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(temb_kernel<IDF_BF16>, grid1d(n), dim3(256), 0, s, t, (unsigned short*)out, B, dim);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(temb_kernel<IDF_F16>, grid1d(n), dim3(256), 0, s, t, (unsigned short*)out, B, dim);
+  else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
+extern "C" int idf_unifusion_embed(const float* text, const float* loc, const float* tmask, const float* lmask,
+                                   const float* null_text, const float* null_loc, const float* freqs, void* out,
+                                   int rows, int text_dim, int D, int dtype, void* stream) {
+  if (!text || !loc || !tmask || !lmask || !null_text || !null_loc || !freqs || !out || rows <= 0 || text_dim <= 0 || D <= 0) return IDF_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)rows * (text_dim + 32 * D);
+  if (dtype == IDF_BF16)
+    hipLaunchKernelGGL(unifusion_embed_kernel<IDF_BF16>, grid1d(n), dim3(256), 0, s, text, loc, tmask, lmask, null_text, null_loc, freqs, (unsigned short*)out, rows, text_dim, D);
+  else if (dtype == IDF_F16)
+    hipLaunchKernelGGL(unifusion_embed_kernel<IDF_F16>, grid1d(n), dim3(256), 0, s, text, loc, tmask, lmask, null_text, null_loc, freqs, (unsigned short*)out, rows, text_dim, D);
+  else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
+extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bias, void* out,
+                           int B, int Cin, int H, int W, int Cout, int dtype, void* stream) {
+  if (!x_nchw || !w || !bias || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8)) return IDF_E_ARG;
+  if (!aligned16(out)) return IDF_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * H * W * (Cout / 8);
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(conv_in_kernel<IDF_BF16>, grid1d(n), dim3(256), 0, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(conv_in_kernel<IDF_F16>, grid1d(n), dim3(256), 0, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout);
+  else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
+extern "C" int idf_cfg_combine(const float* eps_cond, const float* eps_uncond, float guidance, float* e_t, long long n, void* stream) {
+  if (!eps_cond || !eps_uncond || !e_t || n <= 0) return IDF_E_ARG;
+  hipLaunchKernelGGL(cfg_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, eps_cond, eps_uncond, guidance, e_t, n);
+  return idf_launch_status();
+}
+
+extern "C" int idf_plms_update(const float* x, const float* e_t, const float* e1, const float* e2, const float* e3,
+                               const float* e_next, int mode, float a_t, float a_prev, float sqrt_1m_at,
+                               float* x_out, long long n, void* stream) {
+  if (!x || !e_t || !x_out || n <= 0 || mode < 0 || mode > 4) return IDF_E_ARG;
+  if ((mode == 1 && !e_next) || (mode >= 2 && !e1) || (mode >= 3 && !e2) || (mode >= 4 && !e3)) return IDF_E_ARG;
+  // float32 host arithmetic mirrors the reference's torch.full(...).sqrt() on float32 scalars (plms.py:130-144)
+  const float sqrt_at = sqrtf(a_t), sqrt_aprev = sqrtf(a_prev), sqrt_1m_aprev = sqrtf(1.0f - a_prev);
+  hipLaunchKernelGGL(plms_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, e_t, e1, e2, e3, e_next, mode,
+                     sqrt_at, sqrt_aprev, sqrt_1m_at, sqrt_1m_aprev, x_out, n);
+  return idf_launch_status();
+}
+
+extern "C" int idf_mis_merge(const float* lat, const int* boxes, float* out, int n_inst, int B, int C, int H, int W,
+                             int mode, void* stream) {
+  if (!lat || !out || n_inst < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return IDF_E_ARG;
+  if (mode == 1 && !boxes) return IDF_E_ARG;
+  const long long per = (long long)B * C * H * W;
+  hipLaunchKernelGGL(mis_merge_kernel, grid1d(per), dim3(256), 0, (hipStream_t)stream, lat, boxes, out, n_inst, B, C, H, W, mode);
+  return idf_launch_status();
+}
+
+extern "C" int idf_cast_f32_to_16(const float* x, void* out, long long n, int dtype, void* stream) {
+  if (!x || !out || n <= 0) return IDF_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(cast_kernel<IDF_BF16>, grid1d(n), dim3(256), 0, s, x, (unsigned short*)out, n);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(cast_kernel<IDF_F16>, grid1d(n), dim3(256), 0, s, x, (unsigned short*)out, n);
+  else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}

@@ -1,0 +1,221 @@
+// norms.hip -- GroupNorm(32)+SiLU and LayerNorm for gfx950.  HBM-bandwidth-bound kernels:
+//   every global access is a 16-byte (8 x 16-bit) per-lane vector, fully coalesced on the NHWC / token-major layout;
+//   statistics are fp32 (the reference forces fp32 GroupNorm, util.py:223-226).
+// GroupNorm is two launches: (1) per-(batch, row-chunk) partial sums per group, deterministic fixed-order
+// reduction (no float atomics -> bitwise run-to-run reproducible); (2) finalize + normalise + affine (+SiLU).
+// Algorithmic bytes: 2 B read + 2 B written per element (the 2nd read of x is served by L2 / Infinity Cache for the
+// <= 100 MB activations of this UNet).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_MAX_CHUNKS = 64;     // row-chunks per batch element
+
+__host__ __device__ inline int gn_nchunks(int HW) {
+  int n = HW / 32;
+  if (n < 1) n = 1;
+  if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+  return n;
+}
+
+// partial[b][chunk][g][2] = (sum, sumsq) over rows of the chunk
+template <int DT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ partial,
+                                                      int HW, int C, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [2][TY][C]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cpr = C >> 3;                                        // 16-B chunks per row
+  const int TX = cpr < 256 ? cpr : 256;
+  const int TY = 256 / TX;
+  const int tid = threadIdx.x;
+  const int tx = tid % TX, ty = tid / TX;
+  const int rows_per = (HW + nchunks - 1) / nchunks;
+  const int r_begin = chunk * rows_per;
+  const int r_end = min(HW, r_begin + rows_per);
+  const unsigned short* xb = x + (size_t)b * HW * C;
+  float* s_sum = sm;
+  float* s_sq = sm + (size_t)TY * C;
+  if (ty < TY) {
+    for (int cc = tx; cc < cpr; cc += TX) {
+      float s[8], q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+      for (int r = r_begin + ty; r < r_end; r += TY) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(xb + (size_t)r * C + cc * 8);
+        float f[8];
+        unpack8<DT>(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_sum[ty * C + cc * 8 + j] = s[j]; s_sq[ty * C + cc * 8 + j] = q[j]; }
+    }
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS) {
+    const int cpg = C / GN_GROUPS;
+    float a = 0.f, bq = 0.f;
+    for (int y = 0; y < TY; ++y)
+      for (int j = 0; j < cpg; ++j) { a += s_sum[y * C + tid * cpg + j]; bq += s_sq[y * C + tid * cpg + j]; }
+    float* o = partial + (((size_t)b * nchunks + chunk) * GN_GROUPS + tid) * 2;
+    o[0] = a; o[1] = bq;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ partial, int HW, int C, int nchunks,
+                                                      float eps, int silu, int nblk_x) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // scale[C], shift[C], mean[32], rstd[32]
+  float* sc = sm;
+  float* sh = sm + C;
+  float* mean = sm + 2 * C;
+  float* rstd = mean + GN_GROUPS;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / GN_GROUPS;
+  if (tid < GN_GROUPS) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+      const float* pp = partial + (((size_t)b * nchunks + k) * GN_GROUPS + tid) * 2;
+      a += (double)pp[0]; q += (double)pp[1];
+    }
+    const double n = (double)HW * (double)cpg;
+    const double mu = a / n;
+    double var = q / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[tid] = (float)mu;
+    rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int ch = tid; ch < C; ch += 256) {
+    const int g = ch / cpg;
+    const float w = gamma[ch] * rstd[g];
+    sc[ch] = w;
+    sh[ch] = beta[ch] - mean[g] * w;
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  const size_t total = (size_t)HW * cpr;                         // 16-B chunks in this batch element
+  const unsigned short* xb = x + (size_t)b * HW * C;
+  unsigned short* ob = out + (size_t)b * HW * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)nblk_x * 256) {
+    const int cc = (int)(i % cpr);
+    u32x4 v = *reinterpret_cast<const u32x4*>(xb + i * 8);
+    float f[8];
+    unpack8<DT>(v, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = fmaf(f[j], sc[cc * 8 + j], sh[cc * 8 + j]);
+      f[j] = silu ? silu_f(y) : y;
+    }
+    *reinterpret_cast<u32x4*>(ob + i * 8) = pack8<DT>(f);
+  }
+}
+
+// LayerNorm: one wave64 per row, row held in registers (<= 3 x 16-B chunks per lane -> C <= 1536), exact two-pass.
+template <int DT>
+__global__ __launch_bounds__(256) void ln_kernel(const unsigned short* __restrict__ x, int ldx, unsigned short* __restrict__ out,
+                                                int ldo, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cpr = C >> 3;
+  const unsigned short* xr = x + (size_t)row * ldx;
+  float f[3][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cpr) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      unpack8<DT>(v, f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cpr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dlt = f[i][j] - mu; q = fmaf(dlt, dlt, q); }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  unsigned short* orow = out + (size_t)row * ldo;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cpr) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + cc * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + cc * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + cc * 8), b1 = *reinterpret_cast<const f32x4*>(beta + cc * 8 + 4);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = fmaf((f[i][j] - mu) * rs, g0[j], b0[j]);
+        y[j + 4] = fmaf((f[i][j + 4] - mu) * rs, g1[j], b1[j]);
+      }
+      *reinterpret_cast<u32x4*>(orow + cc * 8) = pack8<DT>(y);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long long idf_groupnorm_ws_floats(int B, int HW) {
+  return (long long)B * gn_nchunks(HW) * GN_GROUPS * 2;
+}
+
+extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
+                             int B, int HW, int C, float eps, int silu, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta || !ws) return IDF_E_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || (C % 32) || (C % 8)) return IDF_E_ARG;
+  if (!aligned16(x) || !aligned16(out)) return IDF_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunks = gn_nchunks(HW);
+  const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
+  const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
+  const size_t sm2 = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(float);
+  if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
+  const size_t total = (size_t)HW * cpr;
+  int nblk = (int)((total + 256 * 4 - 1) / (256 * 4));          // >= 4 chunks (64 B) per thread
+  if (nblk < 1) nblk = 1;
+  if (nblk > 256) nblk = 256;
+  dim3 g1(nchunks, B), g2(nblk, B);
+  if (dtype == IDF_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<IDF_BF16>, g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);
+    hipLaunchKernelGGL(gn_apply_kernel<IDF_BF16>, g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,
+                       gamma, beta, ws, HW, C, nchunks, eps, silu, nblk);
+  } else if (dtype == IDF_F16) {
+    hipLaunchKernelGGL(gn_stats_kernel<IDF_F16>, g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);
+    hipLaunchKernelGGL(gn_apply_kernel<IDF_F16>, g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,
+                       gamma, beta, ws, HW, C, nchunks, eps, silu, nblk);
+  } else {
+    return IDF_E_UNSUPPORTED;
+  }
+  return idf_launch_status();
+}
+
+extern "C" int idf_layernorm(const void* x, int ldx, void* out, int ldo, const float* gamma, const float* beta,
+                             int M, int C, float eps, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta) return IDF_E_ARG;
+  if (M <= 0 || C <= 0 || (C % 8) || C > 1536) return IDF_E_ARG;
+  if ((ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out) || !aligned16(gamma) || !aligned16(beta)) return IDF_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((M + 3) / 4);
+  if (dtype == IDF_BF16)
+    hipLaunchKernelGGL(ln_kernel<IDF_BF16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, (unsigned short*)out, ldo, gamma, beta, M, C, eps);
+  else if (dtype == IDF_F16)
+    hipLaunchKernelGGL(ln_kernel<IDF_F16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, (unsigned short*)out, ldo, gamma, beta, M, C, eps);
+  else
+    return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}

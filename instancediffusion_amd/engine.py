@@ -1,0 +1,492 @@
+"""UNet denoise-step executor for MI355X: weight packing, HBM-resident workspace, op sequencing, hipGraph replay.
+
+Replaces the reference's ``UNetModel.forward_single_input`` (openaimodel.py:482-563) and everything below it.
+MI355X-first design decisions (vs the reference's PyTorch module tree):
+  * activations are NHWC / token-major 16-bit matrices for the whole forward -- the reference's NCHW<->token
+    permutes (attention.py:371,376; 13 % of its CPU time) do not exist;
+  * every step-invariant quantity is hoisted into a ``Cond`` object built once per conditioning: UniFusion tokens,
+    cross-attention K/V of the text context, and the fuser's K/V rows of the 184 grounding tokens (LayerNorm is
+    row-wise, so those rows do not depend on x or t);
+  * the gated self-attention attends over two KV segments (visual, grounding) and computes only the visual query rows
+    that attention.py:308 keeps; when the gate scale is 0 the fuser is skipped (exactly 0 * tanh(a) * y);
+  * one forward = a fixed sequence of C-ABI launches on one stream over preallocated buffers, so it is captured
+    once into a hipGraph per (batch, resolution, fuser on/off) and replayed.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .host.attention import SpatialTransformer
+from .host.unet import Downsample, ResBlock, UNetModel, Upsample
+
+OBJ_TOKENS = 184
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """attention.py:36-43: proj -> chunk(2) = (value, gate).  Interleave rows as [32 value | 32 gate] per 64 so that
+    one wave's two 32-wide MFMA column tiles hold value and gate of the SAME output columns (in-register GEGLU)."""
+    n2, k = w.shape
+    n = n2 // 2
+    assert n % 32 == 0
+    wv, wg = w[:n].reshape(n // 32, 32, k), w[n:].reshape(n // 32, 32, k)
+    bv, bg = b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)
+    return torch.cat([wv, wg], dim=1).reshape(n2, k).contiguous(), torch.cat([bv, bg], dim=1).reshape(n2).contiguous()
+
+
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> [Cout, (ky*3+kx)*Cin + ci]  (K order of the implicit-GEMM gather)."""
+    co, ci = w.shape[0], w.shape[1]
+    return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+
+
+class _Lin:
+    __slots__ = ("w", "b")
+
+    def __init__(self, w, b):
+        self.w, self.b = w, b
+
+
+class Cond:
+    """Step-invariant conditioning state for a batch of B samples (built by ``UNetEngine.prepare_cond``)."""
+
+    def __init__(self, B: int):
+        self.B = B
+        self.objs: Optional[torch.Tensor] = None            # [B, 184, 768] 16-bit
+        self.k_ctx: List[torch.Tensor] = []                  # per ST layer [B, 77, C]
+        self.vt_ctx: List[torch.Tensor] = []                 # per ST layer [B, C, 128]
+        self.k_obj: List[torch.Tensor] = []                  # per ST layer [B, 184, C]
+        self.vt_obj: List[torch.Tensor] = []                 # per ST layer [B, C, 192]
+        self.n_ctx = 0
+
+    @staticmethod
+    def cat(conds: Sequence["Cond"]) -> "Cond":
+        out = Cond(sum(c.B for c in conds))
+        out.n_ctx = conds[0].n_ctx
+        out.objs = torch.cat([c.objs for c in conds], 0)
+        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj"):
+            lists = [getattr(c, name) for c in conds]
+            setattr(out, name, [torch.cat(ts, 0) for ts in zip(*lists)])
+        return out
+
+    def select(self, idx: torch.Tensor) -> "Cond":
+        out = Cond(int(idx.numel()))
+        out.n_ctx = self.n_ctx
+        out.objs = self.objs[idx].contiguous()
+        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj"):
+            setattr(out, name, [t[idx].contiguous() for t in getattr(self, name)])
+        return out
+
+
+class UNetEngine:
+    def __init__(self, model: UNetModel, ops=None, dtype: torch.dtype = torch.bfloat16, use_graphs: bool = True):
+        if ops is None:
+            from .ops import HipOps          # raises when libidf_gfx950.so / the GPU is missing: no fallback
+            ops = HipOps(dtype)
+        self.ops = ops
+        self.dtype = ops.dtype
+        self.device = ops.device
+        self.model = model
+        self.heads = model.num_heads
+        self.use_graphs = use_graphs and self.device.type == "cuda"
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+        self._cond_cache: Dict[tuple, Cond] = {}
+        self.fuser_scale = None
+        self._pack(model)
+        self.set_fuser_scale(1.0)
+
+    # =================================================================================================
+    # weight packing (once; HBM-resident 16-bit GEMM images + fp32 vectors)
+    # =================================================================================================
+    def _w16(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=torch.float32).to(self.dtype).contiguous()
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _lin(self, m, with_bias=True) -> _Lin:
+        w = m.weight
+        if w.dim() == 4:
+            w = w.reshape(w.shape[0], w.shape[1])            # 1x1 conv
+        return _Lin(self._w16(w), self._f32(m.bias) if (with_bias and m.bias is not None) else None)
+
+    def _conv(self, m) -> _Lin:
+        return _Lin(self._w16(pack_conv3x3(m.weight.detach().float())), self._f32(m.bias))
+
+    def _pack_ff(self, ff):
+        w, b = pack_geglu(ff.net[0].proj.weight.detach().float(), ff.net[0].proj.bias.detach().float())
+        return dict(w1=self._w16(w), b1=self._f32(b), l2=self._lin(ff.net[2]))
+
+    def _attn(self, a, fuse_qk: bool):
+        d = dict(wv=self._w16(a.to_v.weight), wk=self._w16(a.to_k.weight), wq=self._w16(a.to_q.weight),
+                 out=self._lin(a.to_out[0]))
+        if fuse_qk:
+            d["wqk"] = self._w16(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach()], 0))
+        return d
+
+    def _pack_res(self, rb: ResBlock, emb_w: list, emb_b: list, off: list):
+        p = dict(kind="res", cin=rb.channels, cout=rb.out_channels,
+                 gn1=(self._f32(rb.in_layers[0].weight), self._f32(rb.in_layers[0].bias)),
+                 conv1=self._conv(rb.in_layers[2]),
+                 gn2=(self._f32(rb.out_layers[0].weight), self._f32(rb.out_layers[0].bias)),
+                 conv2=self._conv(rb.out_layers[3]),
+                 skip=None if isinstance(rb.skip_connection, torch.nn.Identity) else self._lin(rb.skip_connection),
+                 emb_off=off[0])
+        emb_w.append(rb.emb_layers[1].weight.detach().float())
+        emb_b.append(rb.emb_layers[1].bias.detach().float())
+        off[0] += rb.out_channels
+        return p
+
+    def _pack_st(self, st: SpatialTransformer, tanh_alphas: list):
+        blk = st.transformer_blocks[0]
+        fz = blk.fuser
+        idx = len(tanh_alphas)
+        tanh_alphas.append(torch.stack([torch.tanh(fz.alpha_attn.detach().float()),
+                                        torch.tanh(fz.alpha_dense.detach().float())]))
+        return dict(kind="st", c=st.in_channels, idx=idx,
+                    norm=(self._f32(st.norm.weight), self._f32(st.norm.bias)),
+                    proj_in=self._lin(st.proj_in), proj_out=self._lin(st.proj_out),
+                    n1=(self._f32(blk.norm1.weight), self._f32(blk.norm1.bias)),
+                    n2=(self._f32(blk.norm2.weight), self._f32(blk.norm2.bias)),
+                    n3=(self._f32(blk.norm3.weight), self._f32(blk.norm3.bias)),
+                    attn1=self._attn(blk.attn1, True), attn2=self._attn(blk.attn2, False), ff=self._pack_ff(blk.ff),
+                    f_lin=self._lin(fz.linear), f_attn=self._attn(fz.attn, True), f_ff=self._pack_ff(fz.ff),
+                    f_n1=(self._f32(fz.norm1.weight), self._f32(fz.norm1.bias)),
+                    f_n2=(self._f32(fz.norm2.weight), self._f32(fz.norm2.bias)))
+
+    def _pack_layers(self, seq, emb_w, emb_b, off, tanh_alphas):
+        out = []
+        for _, layer in seq.items():
+            if isinstance(layer, ResBlock):
+                out.append(self._pack_res(layer, emb_w, emb_b, off))
+            elif isinstance(layer, SpatialTransformer):
+                out.append(self._pack_st(layer, tanh_alphas))
+            elif isinstance(layer, Downsample):
+                out.append(dict(kind="down", conv=self._conv(layer.op)))
+            elif isinstance(layer, Upsample):
+                out.append(dict(kind="up", conv=self._conv(layer.conv)))
+            else:                                             # first conv
+                out.append(dict(kind="conv_in", w=self._f32(layer.weight), b=self._f32(layer.bias)))
+        return out
+
+    def _pack(self, model: UNetModel):
+        emb_w, emb_b, off, tanh_alphas = [], [], [0], []
+        self.te0 = self._lin(model.time_embed[0])
+        self.te2 = self._lin(model.time_embed[2])
+        self.in_blocks = [self._pack_layers(b, emb_w, emb_b, off, tanh_alphas) for b in model.input_blocks]
+        self.mid_block = self._pack_layers(model.middle_block, emb_w, emb_b, off, tanh_alphas)
+        self.out_blocks = [self._pack_layers(b, emb_w, emb_b, off, tanh_alphas) for b in model.output_blocks]
+        self.emb_all = _Lin(self._w16(torch.cat(emb_w, 0)), self._f32(torch.cat(emb_b, 0)))
+        self.emb_total = off[0]
+        self.tanh_alphas = torch.stack(tanh_alphas).to(self.device)            # [n_st, 2] fp32
+        self.gates = torch.zeros_like(self.tanh_alphas)                         # scale * tanh(alpha), read by kernels
+        self.n_st = len(tanh_alphas)
+        self.scaleu = []
+        for i in range(len(model.output_blocks)):
+            b = getattr(model, f"scaleu_b_{i}").detach().float()
+            s = getattr(model, f"scaleu_s_{i}").detach().float()
+            self.scaleu.append((self._f32(torch.tanh(b) + 1.0), self._f32(torch.tanh(s))))
+        self.out_gn = (self._f32(model.out[0].weight), self._f32(model.out[0].bias))
+        oc = model.out[2]
+        wpad = torch.zeros(64, oc.weight.shape[1], 3, 3)
+        wpad[: oc.weight.shape[0]] = oc.weight.detach().float().cpu()
+        bpad = torch.zeros(64)
+        bpad[: oc.bias.shape[0]] = oc.bias.detach().float().cpu()
+        self.out_conv = _Lin(self._w16(pack_conv3x3(wpad)), self._f32(bpad))
+        self.n_out = oc.weight.shape[0]
+        self._pack_tokenizer(model.position_net)
+
+    def repack_first_conv(self, conv):
+        """restore_first_conv_from_SD (openaimodel.py:469-480): only the fp32 first-conv image changes."""
+        p = self.in_blocks[0][0]
+        p["w"].copy_(conv.weight.detach().float())
+        p["b"].copy_(conv.bias.detach().float())
+
+    def _pack_tokenizer(self, pn):
+        self.pn = pn
+        self.tok_mlps = []
+        for i in range(5):
+            seq = pn.linears_list[i]
+            self.tok_mlps.append([self._lin(seq[0]), self._lin(seq[2]), self._lin(seq[4])])
+        self.tok_null = dict(
+            text=self._f32(pn.null_positive_feature), box=self._f32(pn.null_position_feature),
+            point=self._f32(pn.null_point_feature), scribble=self._f32(pn.null_scribble_feature),
+            polygon=self._f32(pn.null_polygon_feature), seg=self._f32(pn.null_seg_feature))
+        self.tok_pos = self._f32(pn.pos_embedding)            # [1, 64, 3072]
+        self.tok_freqs = (100.0 ** (torch.arange(16) / 16)).to(device=self.device, dtype=torch.float32)
+
+    # =================================================================================================
+    # alpha gate (utils/model.py:78-81 set_alpha_scale semantics)
+    # =================================================================================================
+    def set_fuser_scale(self, scale: float):
+        scale = float(scale)
+        if scale != self.fuser_scale:
+            self.fuser_scale = scale
+            self.gates.copy_(self.tanh_alphas * scale)
+
+    def sync_fuser_scale_from_modules(self):
+        from .host.attention import GatedSelfAttentionDense
+        for m in self.model.modules():
+            if type(m) == GatedSelfAttentionDense:
+                self.set_fuser_scale(m.scale)
+                return
+
+    # =================================================================================================
+    # buffers
+    # =================================================================================================
+    def buf(self, role: str, shape, dtype=None, zero=False) -> torch.Tensor:
+        dtype = dtype or self.dtype
+        key = (role, tuple(int(s) for s in shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (self.ops.zeros if zero else self.ops.empty)(key[1], dtype)
+            self._bufs[key] = t
+        return t
+
+    # =================================================================================================
+    # conditioning (step-invariant): UniFusion tokens + per-layer K/V caches
+    # =================================================================================================
+    def tokens(self, g: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """UniFusion.forward in eval mode (text_grounding_net.py:185-313) -> objs [B, 184, 768] (16-bit)."""
+        ops, pn = self.ops, self.pn
+        dev = self.device
+        boxes = g["boxes"].to(dev, torch.float32)
+        B, N, _ = boxes.shape
+        m = g["masks"].to(dev, torch.float32).reshape(B * N)
+        text = g["positive_embeddings"].to(dev, torch.float32).reshape(B * N, -1).contiguous()
+        points = g.get("points")
+        points = ((boxes[..., :2] + boxes[..., 2:]) / 2.0) if points is None else points.to(dev, torch.float32)
+        scribbles = g["scribbles"].to(dev, torch.float32)
+        polygons = g["polygons"].to(dev, torch.float32)
+        drop_point, drop_box, drop_scribble, drop_polygons, drop_segs = pn.eval_drops()
+        zero = torch.zeros_like(m)
+        masks = [
+            zero if drop_box else m,
+            zero if drop_point else m,
+            zero if drop_scribble else ((scribbles.sum(-1).reshape(-1) + m) > 0).float(),
+            zero if drop_polygons else ((polygons.sum(-1).reshape(-1) + m) > 0).float(),
+        ]
+        locs = [boxes.reshape(B * N, 4), points.reshape(B * N, 2), scribbles.reshape(B * N, -1),
+                polygons.reshape(B * N, -1)]
+        nulls = [self.tok_null["box"], self.tok_null["point"], self.tok_null["scribble"], self.tok_null["polygon"]]
+        objs = ops.zeros((B, OBJ_TOKENS, pn.out_dim))
+        for i in range(4):
+            loc = locs[i].contiguous()
+            inp = ops.empty((B * N, text.shape[1] + 32 * loc.shape[1]))
+            ops.unifusion_embed(text, loc, m.contiguous(), masks[i].contiguous(), self.tok_null["text"], nulls[i],
+                                self.tok_freqs, inp)
+            l0, l1, l2 = self.tok_mlps[i]
+            h0 = ops.gemm(inp, l0.w, ops.empty((B * N, l0.w.shape[0])), bias=l0.b, act="silu")
+            h1 = ops.gemm(h0, l1.w, ops.empty((B * N, l1.w.shape[0])), bias=l1.b, act="silu")
+            ops.gemm(h1.view(B, N, -1), l2.w, objs[:, i * N:(i + 1) * N, :], bias=l2.b)
+        # --- segmentation tokens (text_grounding_net.py:226-231, 279-285)
+        segs = g["segs"]
+        use_segs = (not drop_segs) and bool((segs.reshape(B, -1).sum(1) > 0).any())
+        if use_segs:
+            raise NotImplementedError(
+                "instance-mask (ConvNeXt) tokens are not built yet in the HIP path (SURVEY.md §8 config C4); "
+                "refusing to silently substitute the null feature")
+        seg_in = (self.tok_null["seg"].view(1, 1, -1) + self.tok_pos).reshape(64, -1)        # null path, batch-indep.
+        seg16 = ops.cast16(seg_in.contiguous(), ops.empty(seg_in.shape))
+        l0, l1, l2 = self.tok_mlps[4]
+        h0 = ops.gemm(seg16, l0.w, ops.empty((64, l0.w.shape[0])), bias=l0.b, act="silu")
+        h1 = ops.gemm(h0, l1.w, ops.empty((64, l1.w.shape[0])), bias=l1.b, act="silu")
+        seg_tok = ops.gemm(h1, l2.w, ops.empty((64, l2.w.shape[0])), bias=l2.b)
+        objs[:, 4 * N:, :] = seg_tok.unsqueeze(0)
+        return objs
+
+    def _st_layers(self):
+        for blk in self.in_blocks + [self.mid_block] + self.out_blocks:
+            for p in blk:
+                if p["kind"] == "st":
+                    yield p
+
+    def prepare_cond(self, context: torch.Tensor, grounding: Dict[str, torch.Tensor]) -> Cond:
+        ops = self.ops
+        B, n_ctx, cd = context.shape
+        c = Cond(B)
+        c.n_ctx = n_ctx
+        c.objs = self.tokens(grounding)
+        ctx16 = ops.cast16(context.to(self.device, torch.float32).contiguous(), ops.empty((B, n_ctx, cd)))
+        ld_ctx, ld_obj = _round_up(n_ctx, 64), _round_up(OBJ_TOKENS, 64)
+        for p in self._st_layers():
+            C = p["c"]
+            a2, fa = p["attn2"], p["f_attn"]
+            k = ops.gemm(ctx16.view(B * n_ctx, cd), a2["wk"], ops.empty((B * n_ctx, C))).view(B, n_ctx, C)
+            vt = ops.zeros((B, C, ld_ctx))
+            ops.gemm(a2["wv"], ctx16, vt[:, :, :n_ctx])
+            c.k_ctx.append(k)
+            c.vt_ctx.append(vt)
+            o = ops.gemm(c.objs.view(B * OBJ_TOKENS, -1), p["f_lin"].w, ops.empty((B * OBJ_TOKENS, C)), bias=p["f_lin"].b)
+            ln = ops.layernorm(o, ops.empty((B * OBJ_TOKENS, C)), *p["f_n1"])
+            ko = ops.gemm(ln, fa["wk"], ops.empty((B * OBJ_TOKENS, C))).view(B, OBJ_TOKENS, C)
+            vo = ops.zeros((B, C, ld_obj))
+            ops.gemm(fa["wv"], ln.view(B, OBJ_TOKENS, C), vo[:, :, :OBJ_TOKENS])
+            c.k_obj.append(ko)
+            c.vt_obj.append(vo)
+        return c
+
+    # =================================================================================================
+    # forward
+    # =================================================================================================
+    def _res(self, p, x, emb_all, out_role):
+        ops = self.ops
+        B, H, W, Cin = x.shape
+        Cout = p["cout"]
+        g = ops.groupnorm(x, self.buf("gn", x.shape), p["gn1"][0], p["gn1"][1], 1e-5, True)
+        rb = emb_all[:, p["emb_off"]:p["emb_off"] + Cout]
+        h1 = ops.conv3x3(g, p["conv1"].w, self.buf("rb.h1", (B, H, W, Cout)), bias=p["conv1"].b, rowbias=rb)
+        g2 = ops.groupnorm(h1, self.buf("gn", h1.shape), p["gn2"][0], p["gn2"][1], 1e-5, True)
+        if p["skip"] is not None:
+            xs = ops.gemm(x.view(B * H * W, Cin), p["skip"].w, self.buf("rb.skip", (B * H * W, Cout)),
+                          bias=p["skip"].b).view(B, H, W, Cout)
+        else:
+            xs = x
+        return ops.conv3x3(g2, p["conv2"].w, self.buf(out_role, (B, H, W, Cout)), bias=p["conv2"].b, res=xs)
+
+    def _self_attn(self, a, x2, ln, B, N, C, kv_extra=None):
+        """x2 [B*N, C] residual stream, ln = LayerNorm(x2).  Returns the attention output [B, N, C] (pre out-proj)."""
+        ops = self.ops
+        qk = ops.gemm(ln, a["wqk"], self.buf("st.qk", (B * N, 2 * C))).view(B, N, 2 * C)
+        ldv = _round_up(N, 64)
+        vt = self.buf("st.vt", (B, C, ldv), zero=True)
+        ops.gemm(a["wv"], ln.view(B, N, C), vt[:, :, :N])
+        att = self.buf("st.att", (B, N, C))
+        if kv_extra is None:
+            ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads)
+        else:
+            ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads, k1=kv_extra[0], vt1=kv_extra[1],
+                          n1=OBJ_TOKENS)
+        return att
+
+    def _ff(self, f, x2, ln, M, C, gate=None):
+        ops = self.ops
+        mid = ops.gemm(ln, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True)
+        return ops.gemm(mid, f["l2"].w, x2, bias=f["l2"].b, res=x2, gate=gate)
+
+    def _st(self, p, x, cond: Cond, fuser_on: bool):
+        ops = self.ops
+        B, H, W, C = x.shape
+        N, M = H * W, B * H * W
+        g = ops.groupnorm(x, self.buf("gn", x.shape), p["norm"][0], p["norm"][1], 1e-6, False)
+        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b)
+        lnb = self.buf("st.ln", (M, C))
+        # --- self attention (attention.py:334)
+        ln = ops.layernorm(y, lnb, *p["n1"])
+        att = self._self_attn(p["attn1"], y, ln, B, N, C)
+        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y)
+        # --- gated self attention over [visual ; grounding tokens] (attention.py:304-311)
+        if fuser_on:
+            i = p["idx"]
+            ln = ops.layernorm(y, lnb, *p["f_n1"])
+            att = self._self_attn(p["f_attn"], y, ln, B, N, C, kv_extra=(cond.k_obj[i], cond.vt_obj[i]))
+            ops.gemm(att.view(M, C), p["f_attn"]["out"].w, y, bias=p["f_attn"]["out"].b, res=y, gate=self.gates[i, 0:1])
+            ln = ops.layernorm(y, lnb, *p["f_n2"])
+            self._ff(p["f_ff"], y, ln, M, C, gate=self.gates[i, 1:2])
+        # --- cross attention (attention.py:336)
+        i = p["idx"]
+        ln = ops.layernorm(y, lnb, *p["n2"])
+        q = ops.gemm(ln, p["attn2"]["wq"], self.buf("st.q", (M, C))).view(B, N, C)
+        att = self.buf("st.att", (B, N, C))
+        ops.attention(q, cond.k_ctx[i], cond.vt_ctx[i], cond.n_ctx, att, self.heads)
+        ops.gemm(att.view(M, C), p["attn2"]["out"].w, y, bias=p["attn2"]["out"].b, res=y)
+        # --- feed forward (attention.py:337)
+        ln = ops.layernorm(y, lnb, *p["n3"])
+        self._ff(p["ff"], y, ln, M, C)
+        # --- proj_out + x_in (attention.py:378-379), in place on the block input
+        ops.gemm(y, p["proj_out"].w, x.view(M, C), bias=p["proj_out"].b, res=x.view(M, C))
+        return x
+
+    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role):
+        for j, p in enumerate(layers):
+            k = p["kind"]
+            if k == "conv_in":
+                B, _, H, W = x_nchw.shape
+                h = self.ops.conv_in(x_nchw, p["w"], p["b"], self.buf(out_role, (B, H, W, p["w"].shape[0])))
+            elif k == "res":
+                h = self._res(p, h, emb_all, out_role)
+            elif k == "st":
+                h = self._st(p, h, cond, fuser_on)
+            elif k == "down":
+                B, H, W, C = h.shape
+                h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role, (B, (H + 1) // 2, (W + 1) // 2, C)),
+                                     bias=p["conv"].b, stride=2)
+            elif k == "up":
+                B, H, W, C = h.shape
+                h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role + ".up", (B, 2 * H, 2 * W, C)),
+                                     bias=p["conv"].b, upsample=1)
+        return h
+
+    def _forward_ops(self, x: torch.Tensor, t_f32: torch.Tensor, cond: Cond, eps: torch.Tensor, fuser_on: bool):
+        """Enqueue one UNet forward (openaimodel.py:482-563).  x [B,4,H,W] fp32, t_f32 [B], eps [B,4,H,W] fp32."""
+        ops = self.ops
+        B = x.shape[0]
+        mc = self.model.model_channels
+        te = ops.timestep_embedding(t_f32, self.buf("temb.sin", (B, mc)))
+        e1 = ops.gemm(te, self.te0.w, self.buf("temb.1", (B, 4 * mc)), bias=self.te0.b, act="silu")
+        es = ops.gemm(e1, self.te2.w, self.buf("temb.2", (B, 4 * mc)), bias=self.te2.b, act="silu")   # silu(emb)
+        emb_all = ops.gemm(es, self.emb_all.w, self.buf("temb.all", (B, self.emb_total)), bias=self.emb_all.b)
+        hs = []
+        h = None
+        for i, layers in enumerate(self.in_blocks):
+            h = self._run_block(layers, h, x, emb_all, cond, fuser_on, f"in{i}")
+            hs.append(h)
+        h = self._run_block(self.mid_block, h, x, emb_all, cond, fuser_on, "mid")
+        for i, layers in enumerate(self.out_blocks):
+            skip = hs.pop()
+            Bq, H, W, Ch = h.shape
+            cat = ops.scaleu_concat(h, skip, self.buf("cat", (Bq, H, W, Ch + skip.shape[-1])), *self.scaleu[i])
+            h = self._run_block(layers, cat, x, emb_all, cond, fuser_on, f"out{i}")
+        g = ops.groupnorm(h, self.buf("gn", h.shape), self.out_gn[0], self.out_gn[1], 1e-5, True)
+        ops.conv3x3(g, self.out_conv.w, eps, bias=self.out_conv.b, n_valid=self.n_out)
+        return eps
+
+    def forward_cond(self, x: torch.Tensor, t: torch.Tensor, cond: Cond, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """eps = UNet(x, t | cond).  Replays a captured hipGraph when available."""
+        B, Cx, H, W = x.shape
+        assert cond.B == B
+        fuser_on = self.fuser_scale != 0.0
+        key = (B, H, W, id(cond), fuser_on)
+        x_s = self.buf("io.x", x.shape, torch.float32)
+        t_s = self.buf("io.t", (B,), torch.float32)
+        eps_s = self.buf("io.eps", (B, self.n_out, H, W), torch.float32)
+        x_s.copy_(x)
+        t_s.copy_(t)
+        if not self.use_graphs:
+            self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
+        else:
+            entry = self._graphs.get(key)
+            if entry is None:
+                # eager warm-up sizes every buffer, then capture the identical launch sequence
+                self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
+                self._graphs[key] = (graph, cond)            # keep cond alive: the graph reads its tensors
+                entry = self._graphs[key]
+            entry[0].replay()
+        if out is None:
+            return eps_s.clone()
+        out.copy_(eps_s)
+        return out
+
+    # ---- reference-style single call: model(input_dict) -----------------------------------------------
+    def forward(self, x, timesteps, context, grounding) -> torch.Tensor:
+        self.sync_fuser_scale_from_modules()
+        key = (context.data_ptr(), context._version, tuple(context.shape)) + tuple(
+            (k, v.data_ptr(), v._version) for k, v in sorted(grounding.items()) if torch.is_tensor(v))
+        cond = self._cond_cache.get(key)
+        if cond is None:
+            if len(self._cond_cache) > 64:
+                self._cond_cache.clear()
+            cond = self.prepare_cond(context, grounding)
+            cond._keepalive = (context, grounding)           # data_ptr keys stay unique while these live
+            self._cond_cache[key] = cond
+        return self.forward_cond(x.to(self.device, torch.float32), timesteps.to(self.device), cond)

@@ -1,0 +1,230 @@
+"""Tensor-level wrappers over the C ABI (``include/idf.h``): derive pointers / leading dimensions / strides from
+(possibly strided) torch views and enqueue the HIP kernel on torch's current stream.
+
+PyTorch here is plumbing only (device memory + stream); every numeric op is a hand-written gfx950 kernel.
+``HipOps()`` raises if the shared library is missing or no GPU is visible -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_GATE, EPI_GEGLU, EPI_GELU, EPI_OUT_F32, EPI_OUT_NCHW, EPI_RES, EPI_ROWBIAS, EPI_SILU)
+
+_DT = {torch.bfloat16: _lib.IDF_BF16, torch.float16: _lib.IDF_F16}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _rows2d(t: torch.Tensor):
+    """(ld, batch_stride) of a [.., R, Ccols] view whose last dim is contiguous."""
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "last dim must be contiguous"
+    return t.stride(-2), (t.stride(0) if t.dim() == 3 else 0)
+
+
+class HipOps:
+    """The product backend.  One instance per compute dtype (bf16 default, fp16 supported by every kernel)."""
+
+    def __init__(self, dtype: torch.dtype = torch.bfloat16, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible: the InstanceDiffusion HIP path needs a GPU (no CPU fallback)")
+        self.dtype = dtype
+        self.dt = _DT[dtype]
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self._ws = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _workspace(self, key, nfloats: int) -> torch.Tensor:
+        w = self._ws.get(key)
+        if w is None or w.numel() < nfloats:
+            w = torch.empty(int(nfloats), dtype=torch.float32, device=self.device)
+            self._ws[key] = w
+        return w
+
+    def empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or self.dtype, device=self.device)
+
+    # ------------------------------------------------------------------------------------------------
+    def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None,
+             act: Optional[str] = None, geglu: bool = False):
+        """out[..,M,N] = epi(a[..,M,K] @ w[..,N,K]^T).  2-D or batched 3-D views; a/w may be shared (2-D) in a
+        batched call.  geglu: ``w``/``bias`` are in the packed [32 value | 32 gate] row order, out has N/2 cols."""
+        batched = out.dim() == 3
+        M, K = a.shape[-2], a.shape[-1]
+        N = w.shape[-2]
+        assert w.shape[-1] == K
+        lda, sA = _rows2d(a)
+        ldw, sW = _rows2d(w)
+        ldo, sO = _rows2d(out)
+        epi = 0
+        if bias is not None:
+            epi |= EPI_BIAS
+        if rowbias is not None:
+            epi |= EPI_ROWBIAS
+        ldr = sR = 0
+        if res is not None:
+            epi |= EPI_RES
+            ldr, sR = _rows2d(res)
+        if gate is not None:
+            epi |= EPI_GATE
+        if act == "silu":
+            epi |= EPI_SILU
+        elif act == "gelu":
+            epi |= EPI_GELU
+        elif act is not None:
+            raise ValueError(act)
+        if geglu:
+            epi |= EPI_GEGLU
+            assert out.shape[-1] == N // 2
+        else:
+            assert out.shape[-1] == N and out.shape[-2] == M
+        if out.dtype == torch.float32:
+            epi |= EPI_OUT_F32
+        args = _lib.GemmArgs(
+            A=a.data_ptr(), W=w.data_ptr(), out=out.data_ptr(),
+            bias=None if bias is None else bias.data_ptr(),
+            rowbias=None if rowbias is None else rowbias.data_ptr(),
+            res=None if res is None else res.data_ptr(),
+            gate=None if gate is None else gate.data_ptr(),
+            M=M, N=N, K=K, lda=lda, ldw=ldw, ldo=ldo, ldr=ldr,
+            ld_rowbias=0 if rowbias is None else rowbias.stride(-2), rows_per_batch=rows_per_batch,
+            batch=out.shape[0] if batched else 1, strideA=sA, strideW=sW, strideO=sO, strideR=sR,
+            epi=epi, dtype=self.dt)
+        _lib.check(self.lib.idf_gemm(C.byref(args), self._stream()), "idf_gemm")
+        return out
+
+    def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
+        """x [B,H,W,Cin] view (channel-contiguous), w [Cout, 9*Cin]; out [B,Ho,Wo,Cout] 16-bit, or fp32 NCHW
+        [B,n_valid,Ho,Wo] when ``n_valid`` > 0 (final conv)."""
+        B, H, W_, Cin = x.shape
+        assert x.stride(-1) == 1 and x.stride(1) == W_ * x.stride(2) and x.stride(0) == H * x.stride(1)
+        Cout = w.shape[0]
+        epi = 0
+        if bias is not None:
+            epi |= EPI_BIAS
+        if rowbias is not None:
+            epi |= EPI_ROWBIAS
+        if res is not None:
+            epi |= EPI_RES
+        if n_valid:
+            epi |= EPI_OUT_NCHW
+            assert out.dtype == torch.float32 and out.is_contiguous()
+            ldo = 0
+        else:
+            ldo = out.stride(2)
+        args = _lib.ConvArgs(
+            x=x.data_ptr(), W=w.data_ptr(), out=out.data_ptr(),
+            bias=None if bias is None else bias.data_ptr(),
+            rowbias=None if rowbias is None else rowbias.data_ptr(),
+            res=None if res is None else res.data_ptr(),
+            B=B, Hin=H, Win=W_, Cin=Cin, Cout=Cout, stride=stride, upsample=upsample,
+            ldx=x.stride(2), ldo=ldo, ldr=0 if res is None else res.stride(2),
+            ld_rowbias=0 if rowbias is None else rowbias.stride(-2), n_valid=n_valid, epi=epi, dtype=self.dt)
+        _lib.check(self.lib.idf_conv3x3(C.byref(args), self._stream()), "idf_conv3x3")
+        return out
+
+    def conv_in(self, x_nchw, w, bias, out):
+        B, Cin, H, W_ = x_nchw.shape
+        assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and out.is_contiguous()
+        _lib.check(self.lib.idf_conv_in(_p(x_nchw), _p(w), _p(bias), _p(out), B, Cin, H, W_, out.shape[-1], self.dt,
+                                        self._stream()), "idf_conv_in")
+        return out
+
+    def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0):
+        """q [B,Nq,C] view, k [B,n,C] view, vt [B,C,ld>=ceil64(n)], out [B,Nq,C] view."""
+        B, Nq, Cc = q.shape
+        d = Cc // heads
+        a = _lib.AttnArgs(
+            q=q.data_ptr(), ldq=q.stride(1), strideQ=q.stride(0), nq=Nq,
+            k0=k0.data_ptr(), ldk0=k0.stride(1), strideK0=k0.stride(0),
+            vt0=vt0.data_ptr(), ldv0=vt0.stride(1), strideV0=vt0.stride(0), n0=n0,
+            k1=None if k1 is None else k1.data_ptr(), ldk1=0 if k1 is None else k1.stride(1),
+            strideK1=0 if k1 is None else k1.stride(0),
+            vt1=None if vt1 is None else vt1.data_ptr(), ldv1=0 if vt1 is None else vt1.stride(1),
+            strideV1=0 if vt1 is None else vt1.stride(0), n1=n1,
+            out=out.data_ptr(), ldo=out.stride(1), strideO=out.stride(0),
+            B=B, H=heads, d=d, scale=float(d) ** -0.5, dtype=self.dt)
+        _lib.check(self.lib.idf_attention(C.byref(a), self._stream()), "idf_attention")
+        return out
+
+    def groupnorm(self, x, out, gamma, beta, eps, silu):
+        """x/out [B, HW, C] (or [B,H,W,C]) contiguous."""
+        assert x.is_contiguous() and out.is_contiguous()
+        B, Cc = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * Cc)
+        ws = self._workspace("gn", self.lib.idf_groupnorm_ws_floats(B, HW))
+        _lib.check(self.lib.idf_groupnorm(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), B, HW, Cc, float(eps),
+                                          int(bool(silu)), self.dt, self._stream()), "idf_groupnorm")
+        return out
+
+    def layernorm(self, x, out, gamma, beta, eps=1e-5):
+        """x/out [M, C] views (last dim contiguous)."""
+        M, Cc = x.shape
+        _lib.check(self.lib.idf_layernorm(_p(x), x.stride(0), _p(out), out.stride(0), _p(gamma), _p(beta), M, Cc,
+                                          float(eps), self.dt, self._stream()), "idf_layernorm")
+        return out
+
+    def scaleu_concat(self, h, skip, out, hscale, sm1):
+        B, H, W_, Ch = h.shape
+        Cs = skip.shape[-1]
+        assert h.is_contiguous() and skip.is_contiguous() and out.is_contiguous() and out.shape[-1] == Ch + Cs
+        ws = self._workspace("scaleu", B * Cs * 8)
+        _lib.check(self.lib.idf_scaleu_concat(_p(h), _p(skip), _p(out), _p(hscale), _p(sm1), _p(ws), B, H, W_, Ch, Cs,
+                                              self.dt, self._stream()), "idf_scaleu_concat")
+        return out
+
+    def timestep_embedding(self, t_f32, out):
+        B, dim = out.shape
+        _lib.check(self.lib.idf_timestep_embedding(_p(t_f32), _p(out), B, dim, self.dt, self._stream()),
+                   "idf_timestep_embedding")
+        return out
+
+    def unifusion_embed(self, text, loc, tmask, lmask, null_text, null_loc, freqs, out):
+        rows, text_dim = text.shape
+        D = loc.shape[-1]
+        assert out.is_contiguous() and out.shape == (rows, text_dim + 32 * D)
+        for t in (text, loc, tmask, lmask, null_text, null_loc, freqs):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(self.lib.idf_unifusion_embed(_p(text), _p(loc), _p(tmask), _p(lmask), _p(null_text), _p(null_loc),
+                                                _p(freqs), _p(out), rows, text_dim, D, self.dt, self._stream()),
+                   "idf_unifusion_embed")
+        return out
+
+    def cfg_combine(self, e_cond, e_uncond, guidance, out):
+        _lib.check(self.lib.idf_cfg_combine(_p(e_cond), _p(e_uncond), float(guidance), _p(out), out.numel(),
+                                            self._stream()), "idf_cfg_combine")
+        return out
+
+    def plms_update(self, x, e_t, old, e_next, mode, a_t, a_prev, sqrt_1m_at, out):
+        e1 = old[-1] if len(old) >= 1 else None
+        e2 = old[-2] if len(old) >= 2 else None
+        e3 = old[-3] if len(old) >= 3 else None
+        _lib.check(self.lib.idf_plms_update(_p(x), _p(e_t), _p(e1), _p(e2), _p(e3), _p(e_next), int(mode), float(a_t),
+                                            float(a_prev), float(sqrt_1m_at), _p(out), out.numel(), self._stream()),
+                   "idf_plms_update")
+        return out
+
+    def mis_merge(self, lat, boxes_i32, out, mode):
+        n1, B, Cc, H, W_ = lat.shape
+        assert lat.is_contiguous() and out.is_contiguous()
+        _lib.check(self.lib.idf_mis_merge(_p(lat), _p(boxes_i32), _p(out), n1 - 1, B, Cc, H, W_, int(mode),
+                                          self._stream()), "idf_mis_merge")
+        return out
+
+    def cast16(self, x_f32, out):
+        assert x_f32.is_contiguous() and out.is_contiguous()
+        _lib.check(self.lib.idf_cast_f32_to_16(_p(x_f32), _p(out), out.numel(), self.dt, self._stream()),
+                   "idf_cast_f32_to_16")
+        return out

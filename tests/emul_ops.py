@@ -1,0 +1,200 @@
+"""CPU emulation of the C-ABI op set -- TEST DOUBLE ONLY (lives under tests/, never imported by the product).
+
+Purpose: run the *host logic* of the engine (weight packing, op sequencing, buffer aliasing, Cond caches,
+sampler control flow) on a machine without a GPU, with the same 16-bit storage rounding points as the HIP kernels,
+so that (a) orchestration bugs are caught by the CPU suite and (b) the expected bf16-vs-fp32 error is known before
+going to the GPU.  The product path (`instancediffusion_amd.ops.HipOps`) has no such fallback and raises without
+the HIP library.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class EmulOps:
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+        self.device = torch.device("cpu")
+        self.calls = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    def empty(self, shape, dtype=None):
+        # poison fresh buffers so that reads of never-written memory are caught
+        t = torch.empty(shape, dtype=dtype or self.dtype)
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        return t
+
+    def zeros(self, shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or self.dtype)
+
+    # ----------------------------------------------------------------------------------------------
+    def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None, act=None, geglu=False):
+        self._count("gemm")
+        assert a.dtype == self.dtype and w.dtype == self.dtype
+        assert a.shape[-1] % 64 == 0, "K % 64"
+        acc = torch.matmul(a.float(), w.float().transpose(-1, -2))
+        if geglu:
+            n2 = acc.shape[-1]
+            acc = acc + bias
+            blocks = acc.reshape(*acc.shape[:-1], n2 // 64, 2, 32)
+            v = blocks[..., 0, :] * F.gelu(blocks[..., 1, :])
+            out.copy_(v.reshape(*acc.shape[:-1], n2 // 2))
+            return out
+        if bias is not None:
+            acc = acc + bias
+        if rowbias is not None:
+            M = acc.shape[-2]
+            idx = torch.arange(M) // rows_per_batch
+            acc = acc + rowbias.float()[idx]
+        if act == "silu":
+            acc = F.silu(acc)
+        elif act == "gelu":
+            acc = F.gelu(acc)
+        if res is not None:
+            r = res.float()
+            acc = r + (gate.float() * acc if gate is not None else acc)
+        out.copy_(acc)
+        return out
+
+    def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
+        self._count("conv3x3")
+        B, H, W_, Cin = x.shape
+        assert Cin % 64 == 0
+        Cout = w.shape[0]
+        wt = w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        xi = x.float().permute(0, 3, 1, 2)
+        if upsample:
+            xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+        y = F.conv2d(xi, wt, None, stride=stride, padding=1)
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        if rowbias is not None:
+            y = y + rowbias.float()[:, :, None, None]
+        if res is not None:
+            y = y + res.float().permute(0, 3, 1, 2)
+        if n_valid:
+            out.copy_(y[:, :n_valid])
+        else:
+            out.copy_(y.permute(0, 2, 3, 1))
+        return out
+
+    def conv_in(self, x_nchw, w, bias, out):
+        self._count("conv_in")
+        out.copy_(F.conv2d(x_nchw, w, bias, padding=1).permute(0, 2, 3, 1))
+        return out
+
+    def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0):
+        self._count("attention")
+        B, Nq, C = q.shape
+        d = C // heads
+        assert vt0.shape[-1] >= (n0 + 63) // 64 * 64
+        k = k0.float()[:, :n0]
+        v = vt0.float()[:, :, :n0].transpose(1, 2)
+        if n1:
+            assert vt1.shape[-1] >= (n1 + 63) // 64 * 64
+            k = torch.cat([k, k1.float()[:, :n1]], 1)
+            v = torch.cat([v, vt1.float()[:, :, :n1].transpose(1, 2)], 1)
+        M = k.shape[1]
+        qh = q.float().reshape(B, Nq, heads, d).permute(0, 2, 1, 3)
+        kh = k.reshape(B, M, heads, d).permute(0, 2, 1, 3)
+        vh = v.reshape(B, M, heads, d).permute(0, 2, 1, 3)
+        s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+        mx = s.max(-1, keepdim=True).values
+        p = torch.exp(s - mx)
+        l = p.sum(-1, keepdim=True)
+        p16 = p.to(self.dtype).float()             # the kernel packs P to 16-bit before P.V
+        o = torch.matmul(p16, vh) / l
+        out.copy_(o.permute(0, 2, 1, 3).reshape(B, Nq, C))
+        return out
+
+    def groupnorm(self, x, out, gamma, beta, eps, silu):
+        self._count("groupnorm")
+        B, C = x.shape[0], x.shape[-1]
+        xi = x.float().reshape(B, -1, C).permute(0, 2, 1)
+        y = F.group_norm(xi, 32, gamma, beta, eps)
+        if silu:
+            y = F.silu(y)
+        out.copy_(y.permute(0, 2, 1).reshape(x.shape))
+        return out
+
+    def layernorm(self, x, out, gamma, beta, eps=1e-5):
+        self._count("layernorm")
+        out.copy_(F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps))
+        return out
+
+    def scaleu_concat(self, h, skip, out, hscale, sm1):
+        self._count("scaleu_concat")
+        B, H, W_, Ch = h.shape
+        out[..., :Ch] = (h.float() * hscale).to(self.dtype)
+        x = skip.float().permute(0, 3, 1, 2).double()
+        hh = torch.arange(H, dtype=torch.float64)[:, None]
+        ww = torch.arange(W_, dtype=torch.float64)[None, :]
+        low = x.sum((-2, -1), keepdim=True).expand_as(x).clone()
+        for ph in (2 * math.pi * hh / H + 0 * ww, 2 * math.pi * ww / W_ + 0 * hh, 2 * math.pi * (hh / H + ww / W_)):
+            c, s = torch.cos(ph), torch.sin(ph)
+            low = low + (x * c).sum((-2, -1), keepdim=True) * c + (x * s).sum((-2, -1), keepdim=True) * s
+        y = x + sm1.double() * low / (H * W_)
+        out[..., Ch:] = y.permute(0, 2, 3, 1).to(self.dtype)
+        return out
+
+    def timestep_embedding(self, t_f32, out):
+        self._count("timestep_embedding")
+        dim = out.shape[1]
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        a = t_f32[:, None] * freqs[None]
+        out.copy_(torch.cat([torch.cos(a), torch.sin(a)], -1))
+        return out
+
+    def unifusion_embed(self, text, loc, tmask, lmask, null_text, null_loc, freqs, out):
+        self._count("unifusion_embed")
+        parts = []
+        for f in freqs:
+            parts.append(torch.sin(f * loc))
+            parts.append(torch.cos(f * loc))
+        fe = torch.cat(parts, -1)
+        tm, lm = tmask[:, None], lmask[:, None]
+        out.copy_(torch.cat([text * tm + (1 - tm) * null_text, fe * lm + (1 - lm) * null_loc], -1))
+        return out
+
+    def cfg_combine(self, e_cond, e_uncond, guidance, out):
+        out.copy_(e_uncond + guidance * (e_cond - e_uncond))
+        return out
+
+    def plms_update(self, x, e_t, old, e_next, mode, a_t, a_prev, sqrt_1m_at, out):
+        if mode == 0:
+            ep = e_t
+        elif mode == 1:
+            ep = (e_t + e_next) / 2
+        elif mode == 2:
+            ep = (3 * e_t - old[-1]) / 2
+        elif mode == 3:
+            ep = (23 * e_t - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            ep = (55 * e_t - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        a_t = torch.tensor(a_t, dtype=torch.float32)
+        a_prev = torch.tensor(a_prev, dtype=torch.float32)
+        pred = (x - sqrt_1m_at * ep) / a_t.sqrt()
+        out.copy_(a_prev.sqrt() * pred + (1.0 - a_prev).sqrt() * ep)
+        return out
+
+    def mis_merge(self, lat, boxes_i32, out, mode):
+        if mode == 0:
+            out.copy_(lat.mean(0))
+        else:
+            v = lat[0].clone()
+            for k in range(lat.shape[0] - 1):
+                b = boxes_i32[k].tolist()
+                v[:, :, b[0]:b[2], b[1]:b[3]] = lat[k + 1][:, :, b[0]:b[2], b[1]:b[3]]
+            out.copy_(v)
+        return out
+
+    def cast16(self, x_f32, out):
+        out.copy_(x_f32)
+        return out

@@ -1,0 +1,97 @@
+"""Host-logic tests of the engine (no GPU): the op sequence, weight packing, in-place residual aliasing, Cond
+caches and two-segment attention bookkeeping are exercised against the CPU oracle / reference goldens through the
+CPU op emulation in tests/emul_ops.py.  With fp32 storage the engine must agree with the reference to fp32 round-off;
+with bf16 storage the error shows what to expect from the MI355X kernels.
+"""
+import pytest
+import torch
+
+from instancediffusion_amd import synth
+from instancediffusion_amd.engine import UNetEngine, pack_geglu
+from instancediffusion_amd.host.config import unet_kwargs_from_cfg
+from ldm.modules.diffusionmodules.openaimodel import UNetModel
+from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+from tests import cases
+from tests.emul_ops import EmulOps
+
+
+def build_model(cfg):
+    with torch.device("meta"):
+        m = UNetModel(**unet_kwargs_from_cfg(cfg))
+    m = m.to_empty(device="cpu")
+    m.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    return m.eval()
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [
+    ("tiny_box", torch.float32, 3e-4), ("tiny_point", torch.float32, 3e-4), ("mid_box", torch.float32, 3e-4),
+    ("tiny_box", torch.bfloat16, 4e-2), ("mid_box", torch.bfloat16, 4e-2),
+])
+def test_engine_forward_vs_reference(tag, dtype, tol):
+    gold = cases.load_golden(tag)
+    meta = gold["meta"]
+    cfg = cases.cfg_for(meta["cfg"], meta["variant"])
+    inp = cases.build_inputs(meta)
+    model = build_model(cfg)
+    eng = UNetEngine(model, ops=EmulOps(dtype), use_graphs=False)
+    gi = GroundingNetInput()
+    g = gi.prepare(inp["gb"])
+    with torch.no_grad():
+        cond = eng.prepare_cond(inp["context"], g)
+        eps = eng.forward_cond(inp["x"], inp["t"], cond)
+        err = cases.rel_rms(eps, gold["eps_cond"])
+        assert err < tol, f"cond rel-rms {err}"
+        cond0 = eng.prepare_cond(inp["uc"], gi.get_null_input())
+        err = cases.rel_rms(eng.forward_cond(inp["x"], inp["t"], cond0), gold["eps_uncond"])
+        assert err < tol, f"uncond rel-rms {err}"
+        eng.set_fuser_scale(0.3)
+        err = cases.rel_rms(eng.forward_cond(inp["x"], inp["t"], cond), gold["eps_scale03"])
+        assert err < tol, f"scale 0.3 rel-rms {err}"
+        # batched cond+uncond in one forward == the two separate forwards
+        eng.set_fuser_scale(1.0)
+        both = eng.forward_cond(torch.cat([inp["x"], inp["x"]]), torch.cat([inp["t"], inp["t"]]),
+                                type(cond).cat([cond, cond0]))
+        B = inp["x"].shape[0]
+        assert cases.rel_rms(both[:B], gold["eps_cond"]) < tol and cases.rel_rms(both[B:], gold["eps_uncond"]) < tol
+
+
+def test_fuser_skipped_at_scale_zero_is_exact():
+    gold = cases.load_golden("tiny_box")
+    meta = gold["meta"]
+    cfg = cases.cfg_for(meta["cfg"], meta["variant"])
+    inp = cases.build_inputs(meta)
+    model = build_model(cfg)
+    eng = UNetEngine(model, ops=EmulOps(torch.float32), use_graphs=False)
+    g = GroundingNetInput().prepare(inp["gb"])
+    from oracle import ref_cpu
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        cond = eng.prepare_cond(inp["context"], g)
+        eng.set_fuser_scale(0.0)
+        n_att = eng.ops.calls.get("attention", 0)
+        eps = eng.forward_cond(inp["x"], inp["t"], cond)
+        n_st = eng.n_st
+        assert eng.ops.calls["attention"] - n_att == 2 * n_st          # self + cross only: fuser launches skipped
+        objs, _ = ref_cpu.unifusion(sd, cfg, ref_cpu.prepare_grounding(inp["gb"]))
+        ref = ref_cpu.unet_forward(sd, cfg, inp["x"], inp["t"], inp["context"], objs, fuser_scale=0.0)
+    assert cases.rel_rms(eps, ref) < 3e-4
+
+
+def test_pack_geglu_layout():
+    w = torch.arange(128 * 4, dtype=torch.float32).reshape(128, 4)
+    b = torch.arange(128, dtype=torch.float32)
+    wp, bp = pack_geglu(w, b)
+    # packed rows [0:32] = value rows 0..31, [32:64] = gate rows 64..95, [64:96] = value 32..63, [96:128] = gate 96..127
+    assert torch.equal(bp[:32], b[:32]) and torch.equal(bp[32:64], b[64:96])
+    assert torch.equal(bp[64:96], b[32:64]) and torch.equal(bp[96:], b[96:])
+    assert torch.equal(wp[40], w[72])
+
+
+def test_model_forward_refuses_without_hip(monkeypatch):
+    """The product path must fail loudly (no silent CPU fallback) when there is no GPU."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = cases.cfg_for("test_box.yaml", "tiny")
+    model = build_model(cfg)
+    with pytest.raises(RuntimeError):
+        model.engine

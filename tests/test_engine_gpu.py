@@ -1,0 +1,101 @@
+"""End-to-end parity of the HIP UNet engine on a real MI355X against (a) golden outputs of the unmodified
+reference and (b) the live CPU oracle, on the same seeded weights/inputs.
+
+Stated tolerance (anchored on the reference's own bf16-autocast noise floor of 1.55e-2 rel-RMS):
+bf16 storage / fp32 accumulate, per UNet forward: rel-RMS <= 3e-2 and max-abs <= 0.15 * RMS(eps).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 3e-2
+
+
+def _build(cfg):
+    from tests.test_engine_emulated import build_model
+    return build_model(cfg)
+
+
+def _case(tag):
+    from tests import cases
+    gold = cases.load_golden(tag)
+    meta = gold["meta"]
+    cfg = cases.cfg_for(meta["cfg"], meta["variant"])
+    return gold, meta, cfg, cases.build_inputs(meta)
+
+
+def _check(eps, want, what):
+    from tests import cases
+    eps = eps.float().cpu()
+    err = cases.rel_rms(eps, want)
+    mx = float((eps - want).abs().max() / want.pow(2).mean().sqrt())
+    print(f"[parity] {what}: rel-rms {err:.3e}  max-abs/rms {mx:.3e}")
+    assert torch.isfinite(eps).all(), what
+    assert err < FWD_TOL, f"{what}: rel-rms {err}"
+    assert mx < 0.15, f"{what}: max-abs/rms {mx}"
+
+
+@pytest.mark.parametrize("tag", ["tiny_box", "tiny_point", "mid_box"])
+def test_forward_matches_reference_golden(tag):
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    gold, meta, cfg, inp = _case(tag)
+    model = _build(cfg)
+    gi = GroundingNetInput()
+    model.grounding_tokenizer_input = gi
+    g = {k: v.cuda() for k, v in gi.prepare(inp["gb"]).items()}
+    gi.prepare({k: v.cuda() for k, v in inp["gb"].items()})
+    with torch.no_grad():
+        # reference-style entry point: model(input dict)
+        eps = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
+        _check(eps, gold["eps_cond"], f"{tag} cond")
+        eps2 = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
+        assert torch.equal(eps, eps2), "graph replay must be bitwise identical to the eager warm-up"
+        eps_u = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["uc"].cuda()))
+        _check(eps_u, gold["eps_uncond"], f"{tag} uncond (null grounding)")
+        from ldm.modules.attention import GatedSelfAttentionDense
+        for m in model.modules():
+            if type(m) == GatedSelfAttentionDense:
+                m.scale = 0.3
+        eps_s = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
+        _check(eps_s, gold["eps_scale03"], f"{tag} fuser scale 0.3")
+
+
+def test_full_size_forward_matches_reference_golden():
+    """The headline model: SD-1.5 InstanceDiffusion UNet, 1.228 B parameters, 64x64 latent, C1 boxes."""
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    gold, meta, cfg, inp = _case("full_box_c1")
+    model = _build(cfg)
+    gi = GroundingNetInput()
+    model.grounding_tokenizer_input = gi
+    g = {k: v.cuda() for k, v in gi.prepare(inp["gb"]).items()}
+    with torch.no_grad():
+        eps = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
+    _check(eps, gold["eps_cond"], "full C1 cond")
+
+
+def test_forward_matches_live_oracle_other_timestep_and_batch():
+    """Live CPU oracle (not a stored golden): different t per sample, batch 3, fuser off (alpha == 0 stage)."""
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    from instancediffusion_amd import synth
+    from oracle import ref_cpu
+    from tests import cases
+    cfg = cases.cfg_for("test_box.yaml", "mid")
+    model = _build(cfg)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    gb = synth.make_grounding_batch(3, synth.random_boxes(5, g), g)
+    x = torch.randn(3, 4, 16, 16, generator=g)
+    ctx = torch.randn(3, 77, 768, generator=g)
+    t = torch.tensor([901, 441, 21])
+    gi = GroundingNetInput()
+    grounding = gi.prepare(gb)
+    with torch.no_grad():
+        objs, _ = ref_cpu.unifusion(sd, cfg, ref_cpu.prepare_grounding(gb))
+        for scale in (1.0, 0.0):
+            want = ref_cpu.unet_forward(sd, cfg, x, t, ctx, objs, fuser_scale=scale)
+            eng = model.engine
+            eng.set_fuser_scale(scale)
+            cond = eng.prepare_cond(ctx.cuda(), {k: v.cuda() for k, v in grounding.items()})
+            eps = eng.forward_cond(x.cuda(), t.cuda(), cond)
+            _check(eps, want, f"mid live-oracle scale={scale}")

@@ -1,0 +1,316 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point vs a plain PyTorch fp32 reference of the same op
+(tests/emul_ops.EmulOps in fp32) on the same seeded inputs.  Tolerances are relative to the output max:
+bf16 storage, fp32 accumulation -> 2^-7 (one bf16 ulp of the largest element) unless stated; fp32 outputs 1e-5.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 2.0 ** -7
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from instancediffusion_amd.ops import HipOps
+    return HipOps(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from tests.emul_ops import EmulOps
+    return EmulOps(torch.float32)
+
+
+def gen(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def to16(t):
+    return t.to(torch.bfloat16)
+
+
+def relmax(a, b):
+    return float((a.float().cpu() - b.float().cpu()).abs().max() / b.float().abs().max().clamp_min(1e-20))
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (4096, 320, 320), (300, 640, 1280), (77, 64, 768),
+                                   (184, 1280, 768), (64, 1280, 5120), (2, 20160, 1280), (1000, 960, 192)])
+def test_gemm_bias(ops, ref, M, N, K):
+    a, w, b = to16(gen((M, K), 1)), to16(gen((N, K), 2, K ** -0.5)), gen((N,), 3)
+    want = a.float() @ w.float().t() + b
+    out = ops.gemm(dev(a), dev(w), ops.empty((M, N)), bias=dev(b))
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+
+
+def test_gemm_is_transpose_detecting(ops):
+    """A = I-like structure with asymmetric B (guide rule: symmetric inputs hide row/col swaps)."""
+    M = N = K = 128
+    a = torch.eye(M, K)
+    w = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 0.25) / 64.0
+    out = ops.gemm(dev(to16(a)), dev(to16(w)), ops.empty((M, N)))
+    torch.cuda.synchronize()
+    want = to16(a).float() @ to16(w).float().t()
+    assert relmax(out, want) < BF16_TOL
+
+
+@pytest.mark.parametrize("act", [None, "silu", "gelu"])
+def test_gemm_epilogues(ops, act):
+    M, N, K = 520, 320, 640
+    a, w, b = to16(gen((M, K), 4)), to16(gen((N, K), 5, K ** -0.5)), gen((N,), 6)
+    res = to16(gen((M, N), 7))
+    rowb = to16(gen((4, N), 8))
+    gate = torch.tensor([0.37])
+    acc = a.float() @ w.float().t() + b + rowb.float()[torch.arange(M) // 130]
+    if act == "silu":
+        acc = torch.nn.functional.silu(acc)
+    elif act == "gelu":
+        acc = torch.nn.functional.gelu(acc)
+    want = res.float() + 0.37 * acc
+    out = ops.gemm(dev(a), dev(w), ops.empty((M, N)), bias=dev(b), rowbias=dev(rowb), rows_per_batch=130,
+                   res=dev(res), gate=dev(gate), act=act)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+    # in-place residual (out aliases res), as the engine uses it
+    buf = dev(res.clone())
+    ops.gemm(dev(a), dev(w), buf, bias=dev(b), res=buf)
+    torch.cuda.synchronize()
+    assert relmax(buf, res.float() + a.float() @ w.float().t() + b) < BF16_TOL
+
+
+def test_gemm_geglu(ops, ref):
+    from instancediffusion_amd.engine import pack_geglu
+    M, C = 333, 320
+    a = to16(gen((M, C), 9))
+    w, b = gen((8 * C, C), 10, C ** -0.5), gen((8 * C,), 11)
+    w16 = to16(w)
+    h = a.float() @ w16.float().t() + b
+    x, g = h.chunk(2, -1)
+    want = x * torch.nn.functional.gelu(g)
+    wp, bp = pack_geglu(w16.float(), b)
+    out = ops.gemm(dev(a), dev(to16(wp)), ops.empty((M, 4 * C)), bias=dev(bp), geglu=True)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+
+
+def test_gemm_batched_transposed_v(ops):
+    """V^T[b] = Wv . X_b^T with a zero-padded leading dimension (what the attention kernel consumes)."""
+    B, N, C = 3, 77, 320
+    x, wv = to16(gen((B, N, C), 12)), to16(gen((C, C), 13, C ** -0.5))
+    vt = ops.zeros((B, C, 128))
+    ops.gemm(dev(wv), dev(x), vt[:, :, :N])
+    torch.cuda.synchronize()
+    want = torch.einsum("ck,bnk->bcn", wv.float(), x.float())
+    assert relmax(vt[:, :, :N], want) < BF16_TOL
+    assert float(vt[:, :, N:].float().abs().max()) == 0.0
+
+
+def test_gemm_f32_out_and_strided_out(ops):
+    M, N, K = 60, 768, 256
+    a, w = to16(gen((2, 30, K), 14)), to16(gen((N, K), 15, K ** -0.5))
+    objs = ops.zeros((2, 184, N))
+    ops.gemm(dev(a), dev(w), objs[:, 30:60, :])
+    out32 = ops.gemm(dev(a.view(M, K)), dev(w), ops.empty((M, N), torch.float32))
+    torch.cuda.synchronize()
+    want = a.float() @ w.float().t()
+    assert relmax(objs[:, 30:60], want) < BF16_TOL
+    assert float(objs[:, :30].float().abs().max()) == 0.0 and float(objs[:, 60:].float().abs().max()) == 0.0
+    assert relmax(out32, want.view(M, N)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# conv
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [
+    (1, 16, 16, 64, 64, 1, 0), (2, 8, 8, 320, 640, 1, 0), (2, 16, 16, 128, 128, 2, 0), (1, 8, 8, 128, 128, 1, 1),
+    (1, 12, 12, 192, 320, 1, 0), (1, 7, 9, 64, 64, 2, 0), (1, 64, 64, 320, 320, 1, 0)])
+def test_conv3x3(ops, ref, B, H, W, Cin, Cout, stride, up):
+    from instancediffusion_amd.engine import pack_conv3x3
+    x = to16(gen((B, H, W, Cin), 20))
+    w4 = gen((Cout, Cin, 3, 3), 21, (9 * Cin) ** -0.5)
+    b = gen((Cout,), 22)
+    wp = to16(pack_conv3x3(w4))
+    Ho = ((H << up) - 1) // stride + 1
+    Wo = ((W << up) - 1) // stride + 1
+    rowb = to16(gen((B, Cout), 23))
+    res = to16(gen((B, Ho, Wo, Cout), 24))
+    want = ref.conv3x3(x.float(), wp.float(), torch.empty(B, Ho, Wo, Cout), bias=b, rowbias=rowb.float(),
+                       res=res.float(), stride=stride, upsample=up)
+    out = ops.conv3x3(dev(x), dev(wp), ops.empty((B, Ho, Wo, Cout)), bias=dev(b), rowbias=dev(rowb), res=dev(res),
+                      stride=stride, upsample=up)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+
+
+def test_conv3x3_out_nchw(ops, ref):
+    from instancediffusion_amd.engine import pack_conv3x3
+    B, H, W, Cin = 2, 16, 16, 64
+    x = to16(gen((B, H, W, Cin), 25))
+    w4 = torch.zeros(64, Cin, 3, 3)
+    w4[:4] = gen((4, Cin, 3, 3), 26, (9 * Cin) ** -0.5)
+    b = torch.zeros(64)
+    b[:4] = gen((4,), 27)
+    wp = to16(pack_conv3x3(w4))
+    want = ref.conv3x3(x.float(), wp.float(), torch.empty(B, 4, H, W), bias=b, n_valid=4)
+    out = ops.conv3x3(dev(x), dev(wp), ops.empty((B, 4, H, W), torch.float32), bias=dev(b), n_valid=4)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < 1e-4          # fp32 output of bf16 operands: accumulation-order differences only
+
+
+def test_conv_in(ops, ref):
+    x, w, b = gen((2, 4, 16, 16), 28), gen((64, 4, 3, 3), 29, 1 / 6), gen((64,), 30)
+    want = ref.conv_in(x, w, b, torch.empty(2, 16, 16, 64))
+    out = ops.conv_in(dev(x), dev(w), dev(b), ops.empty((2, 16, 16, 64)))
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,d,Nq,n0,n1", [
+    (1, 8, 40, 256, 256, 0), (2, 8, 40, 256, 256, 184), (1, 8, 80, 64, 64, 184), (2, 8, 160, 100, 100, 184),
+    (1, 8, 40, 4096, 4096, 184), (2, 8, 40, 200, 77, 0), (1, 8, 8, 256, 256, 184), (1, 8, 16, 64, 64, 0),
+    (1, 8, 32, 16, 16, 184), (1, 2, 160, 130, 77, 0)])
+def test_attention(ops, ref, B, H, d, Nq, n0, n1):
+    C = H * d
+    q, k0, v0 = to16(gen((B, Nq, C), 40)), to16(gen((B, n0, C), 41)), to16(gen((B, n0, C), 42))
+    ld0 = (n0 + 63) // 64 * 64
+    vt0 = torch.zeros(B, C, ld0, dtype=torch.bfloat16)
+    vt0[:, :, :n0] = v0.transpose(1, 2)
+    kw = {}
+    rkw = {}
+    if n1:
+        k1, v1 = to16(gen((B, n1, C), 43)), to16(gen((B, n1, C), 44))
+        vt1 = torch.full((B, C, 192), float("nan"), dtype=torch.bfloat16)    # pad must be masked by the kernel
+        vt1[:, :, :n1] = v1.transpose(1, 2)
+        kw = dict(k1=dev(k1), vt1=dev(vt1), n1=n1)
+        rkw = dict(k1=k1.float(), vt1=torch.nan_to_num(vt1.float()), n1=n1)
+    want = ref.attention(q.float(), k0.float(), vt0.float(), n0, torch.empty(B, Nq, C), H, **rkw)
+    out = ops.attention(dev(q), dev(k0), dev(vt0), n0, ops.empty((B, Nq, C)), H, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert relmax(out, want) < 2 * BF16_TOL          # P is rounded to bf16 inside the kernel
+
+
+def test_attention_forced_rescale(ops, ref):
+    """Online-softmax rescale branch: a spiked key in a LATE tile must rescale earlier accumulations."""
+    B, H, d, N = 1, 8, 40, 512
+    C = H * d
+    q, k, v = gen((B, N, C), 45), gen((B, N, C), 46), gen((B, N, C), 47)
+    k[:, 400] = q[:, 7] * 4.0                       # row 7 gets a huge score at kv=400 (7th tile)
+    q, k, v = to16(q), to16(k), to16(v)
+    vt = v.transpose(1, 2).contiguous()
+    want = ref.attention(q.float(), k.float(), vt.float(), N, torch.empty(B, N, C), H)
+    out = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < 2 * BF16_TOL
+
+
+def test_attention_strided_qk_views(ops, ref):
+    """q/k as column slices of a fused [B, N, 2C] projection buffer (how the engine calls it)."""
+    B, H, d, N = 2, 8, 40, 320
+    C = H * d
+    qk = to16(gen((B, N, 2 * C), 48))
+    v = to16(gen((B, N, C), 49))
+    vt = v.transpose(1, 2).contiguous()
+    want = ref.attention(qk[:, :, :C].float(), qk[:, :, C:].float(), vt.float(), N, torch.empty(B, N, C), H)
+    dqk = dev(qk)
+    out = ops.attention(dqk[:, :, :C], dqk[:, :, C:], dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < 2 * BF16_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# norms / scaleu / misc
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 64, True), (1, 4096, 320, True), (2, 64, 2560, True),
+                                         (3, 1024, 960, False), (1, 144, 1920, True), (2, 16, 128, False)])
+def test_groupnorm(ops, ref, B, HW, C, silu):
+    x = to16(gen((B, HW, C), 50) * 1.5 + 0.7)
+    gm, bt = 1 + 0.1 * gen((C,), 51), 0.1 * gen((C,), 52)
+    want = ref.groupnorm(x.float(), torch.empty(B, HW, C), gm, bt, 1e-5, silu)
+    out = ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, silu)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+    out2 = ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, silu)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2), "GroupNorm must be bitwise run-to-run deterministic"
+
+
+@pytest.mark.parametrize("M,C", [(4096, 320), (1000, 640), (77, 1280), (5, 64), (184, 128)])
+def test_layernorm(ops, ref, M, C):
+    x = to16(gen((M, C), 53) * 2 + 0.3)
+    gm, bt = 1 + 0.1 * gen((C,), 54), 0.1 * gen((C,), 55)
+    want = ref.layernorm(x.float(), torch.empty(M, C), gm, bt)
+    out = ops.layernorm(dev(x), ops.empty((M, C)), dev(gm), dev(bt))
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+
+
+@pytest.mark.parametrize("B,H,W,Ch,Cs", [(2, 8, 8, 1280, 1280), (1, 64, 64, 320, 320), (1, 16, 16, 1280, 640),
+                                         (2, 12, 12, 128, 64), (1, 24, 48, 64, 64)])
+def test_scaleu_concat(ops, B, H, W, Ch, Cs):
+    from oracle import ref_cpu
+    h, skip = to16(gen((B, H, W, Ch), 56)), to16(gen((B, H, W, Cs), 57) + 0.5)
+    hs, s = torch.tanh(0.3 * gen((Ch,), 58)) + 1, torch.tanh(torch.tensor([-0.4])) + 1
+    # reference algorithm (FFT) in NCHW fp32 on the bf16-rounded inputs
+    want_h = h.float() * hs
+    want_s = ref_cpu.fourier_filter(skip.float().permute(0, 3, 1, 2), 1, s).permute(0, 2, 3, 1)
+    out = ops.scaleu_concat(dev(h), dev(skip), ops.empty((B, H, W, Ch + Cs)), dev(hs), dev(s - 1))
+    torch.cuda.synchronize()
+    assert relmax(out[..., :Ch], want_h) < BF16_TOL
+    assert relmax(out[..., Ch:], want_s) < BF16_TOL
+
+
+def test_small_kernels(ops, ref):
+    from oracle import ref_cpu
+    t = torch.tensor([981.0, 1.0, 500.0])
+    out = ops.timestep_embedding(dev(t), ops.empty((3, 320)))
+    want = ref_cpu.timestep_embedding(t, 320)
+    torch.cuda.synchronize()
+    assert float((out.float().cpu() - want).abs().max()) < 2.0 ** -7
+    # unifusion embed
+    rows, D = 60, 40
+    text, loc = gen((rows, 768), 60), torch.rand(rows, D, generator=torch.Generator().manual_seed(61))
+    tm = (torch.arange(rows) % 3 != 0).float()
+    lm = (torch.arange(rows) % 2 == 0).float()
+    nt, nl = gen((768,), 62), gen((32 * D,), 63)
+    freqs = 100.0 ** (torch.arange(16) / 16)
+    want = ref.unifusion_embed(text, loc, tm, lm, nt, nl, freqs, torch.empty(rows, 768 + 32 * D))
+    out = ops.unifusion_embed(dev(text), dev(loc), dev(tm), dev(lm), dev(nt), dev(nl), dev(freqs),
+                              ops.empty((rows, 768 + 32 * D)))
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+    # cfg + plms + merge (fp32 kernels: 1e-5)
+    ec, eu, x = gen((2, 4, 16, 16), 64), gen((2, 4, 16, 16), 65), gen((2, 4, 16, 16), 66)
+    old = [gen((2, 4, 16, 16), 67 + i) for i in range(3)]
+    et = ops.cfg_combine(dev(ec), dev(eu), 7.5, ops.empty(ec.shape, torch.float32))
+    torch.cuda.synchronize()
+    assert relmax(et, eu + 7.5 * (ec - eu)) < 1e-6
+    a_t, a_prev = 0.0047, 0.0313
+    s1m = float(torch.sqrt(1.0 - torch.tensor(a_t)))
+    for mode in range(5):
+        want = ref.plms_update(x, ec, old, eu, mode, a_t, a_prev, s1m, torch.empty_like(x))
+        got = ops.plms_update(dev(x), dev(ec), [dev(o) for o in old], dev(eu), mode, a_t, a_prev, s1m,
+                              ops.empty(x.shape, torch.float32))
+        torch.cuda.synchronize()
+        assert relmax(got, want) < 1e-5, mode
+    lat = gen((4, 2, 4, 16, 16), 70)
+    boxes = torch.tensor([[1, 2, 9, 12], [4, 0, 16, 5], [0, 0, 3, 3]], dtype=torch.int32)
+    for mode in (0, 1):
+        want = ref.mis_merge(lat, boxes, torch.empty(2, 4, 16, 16), mode)
+        got = ops.mis_merge(dev(lat), dev(boxes), ops.empty((2, 4, 16, 16), torch.float32), mode)
+        torch.cuda.synchronize()
+        assert relmax(got, want) < 1e-6

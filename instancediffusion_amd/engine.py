@@ -55,7 +55,11 @@ class _Lin:
 class Cond:
     """Step-invariant conditioning state for a batch of B samples (built by ``UNetEngine.prepare_cond``)."""
 
+    _next_uid = 0
+
     def __init__(self, B: int):
+        Cond._next_uid += 1
+        self.uid = Cond._next_uid                              # identity for the engine's static-slot binding
         self.B = B
         self.objs: Optional[torch.Tensor] = None            # [B, 184, 768] 16-bit
         self.k_ctx: List[torch.Tensor] = []                  # per ST layer [B, 77, C]
@@ -73,6 +77,25 @@ class Cond:
             lists = [getattr(c, name) for c in conds]
             setattr(out, name, [torch.cat(ts, 0) for ts in zip(*lists)])
         return out
+
+    def _tensors(self):
+        return [self.objs] + self.k_ctx + self.vt_ctx + self.k_obj + self.vt_obj
+
+    def clone(self) -> "Cond":
+        out = Cond(self.B)
+        out.n_ctx = self.n_ctx
+        out.objs = self.objs.clone()
+        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj"):
+            setattr(out, name, [t.clone() for t in getattr(self, name)])
+        return out
+
+    def copy_from(self, other: "Cond"):
+        for dst, src in zip(self._tensors(), other._tensors()):
+            dst.copy_(src)
+
+    def same_layout(self, other: "Cond") -> bool:
+        a, b = self._tensors(), other._tensors()
+        return len(a) == len(b) and all(x.shape == y.shape for x, y in zip(a, b)) and self.n_ctx == other.n_ctx
 
     def select(self, idx: torch.Tensor) -> "Cond":
         out = Cond(int(idx.numel()))
@@ -97,6 +120,8 @@ class UNetEngine:
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
         self._cond_cache: Dict[tuple, Cond] = {}
+        self._slots: Dict[int, Cond] = {}                      # batch size -> static Cond the hipGraphs read from
+        self._slot_bound: Dict[int, int] = {}
         self.fuser_scale = None
         self._pack(model)
         self.set_fuser_scale(1.0)
@@ -447,12 +472,28 @@ class UNetEngine:
         ops.conv3x3(g, self.out_conv.w, eps, bias=self.out_conv.b, n_valid=self.n_out)
         return eps
 
+    def _bind(self, cond: Cond) -> Cond:
+        """Copy ``cond`` into the static per-batch-size slot that captured graphs read (no-op if already bound)."""
+        B = cond.B
+        slot = self._slots.get(B)
+        if slot is None or not slot.same_layout(cond):
+            slot = cond.clone()
+            self._slots[B] = slot
+            self._slot_bound[B] = cond.uid
+            for k in [k for k in self._graphs if k[0] == B]:
+                del self._graphs[k]
+        elif self._slot_bound[B] != cond.uid:
+            slot.copy_from(cond)
+            self._slot_bound[B] = cond.uid
+        return slot
+
     def forward_cond(self, x: torch.Tensor, t: torch.Tensor, cond: Cond, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """eps = UNet(x, t | cond).  Replays a captured hipGraph when available."""
+        """eps = UNet(x, t | cond).  The launch sequence is captured once per (batch, resolution, fuser on/off)
+        into a hipGraph over static buffers and replayed; conditioning is copied into a static slot when it changes."""
         B, Cx, H, W = x.shape
         assert cond.B == B
         fuser_on = self.fuser_scale != 0.0
-        key = (B, H, W, id(cond), fuser_on)
+        key = (B, H, W, fuser_on)
         x_s = self.buf("io.x", x.shape, torch.float32)
         t_s = self.buf("io.t", (B,), torch.float32)
         eps_s = self.buf("io.eps", (B, self.n_out, H, W), torch.float32)
@@ -461,17 +502,17 @@ class UNetEngine:
         if not self.use_graphs:
             self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
         else:
-            entry = self._graphs.get(key)
-            if entry is None:
+            slot = self._bind(cond)
+            graph = self._graphs.get(key)
+            if graph is None:
                 # eager warm-up sizes every buffer, then capture the identical launch sequence
-                self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
+                self._forward_ops(x_s, t_s, slot, eps_s, fuser_on)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
-                self._graphs[key] = (graph, cond)            # keep cond alive: the graph reads its tensors
-                entry = self._graphs[key]
-            entry[0].replay()
+                    self._forward_ops(x_s, t_s, slot, eps_s, fuser_on)
+                self._graphs[key] = graph
+            graph.replay()
         if out is None:
             return eps_s.clone()
         out.copy_(eps_s)

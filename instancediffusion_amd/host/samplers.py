@@ -1,0 +1,270 @@
+"""PLMS sampler and the Multi-instance Sampler (MIS) for the MI355X engine.
+
+Host mirror of ``ldm/models/diffusion/plms.py`` (PLMSSampler) and ``plms_instance.py`` (PLMSSamplerInst): same
+constructor / ``sample()`` API, same schedule, same update rule and quirks, different execution plan:
+
+  * the conditional and unconditional (classifier-free guidance) evaluations of a step run as ONE batched UNet
+    forward; in MIS phase 1 all N+1 instance trajectories (x images) advance together in one batch -- the reference
+    runs those 2(N+1) forwards per step serially (plms_instance.py:86-104);
+  * everything step-invariant lives in ``engine.Cond`` objects built once per ``sample()`` call;
+  * latents, eps history and the PLMS/CFG arithmetic stay on the GPU in fp32 (fused kernels);
+  * with ``torch.distributed`` initialised (one process per GPU, RCCL), MIS phase 1 is sharded over
+    (instance, image) work units, the merge (plms_instance.py:135) is ONE all-reduce of the per-rank partial sums
+    (64 KiB per image), and phase 2 is sharded over images.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .diffusion import make_ddim_timesteps
+
+
+class _PLMSBase(object):
+    def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None):
+        super().__init__()
+        self.diffusion = diffusion
+        self.model = model
+        self.device = diffusion.betas.device
+        self.ddpm_num_timesteps = diffusion.num_timesteps
+        self.schedule = schedule
+        self.alpha_generator_func = alpha_generator_func
+        self.set_alpha_scale = set_alpha_scale
+
+    # ---- schedule (plms.py:25-62; util.py:55-83) ------------------------------------------------------
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=False):
+        if ddim_eta != 0:
+            raise ValueError('ddim_eta must be 0 for PLMS')
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        ac = self.diffusion.alphas_cumprod.detach().to(torch.float32).cpu()
+        assert ac.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
+        # float32 values, exactly as the reference's float32 buffers (make_ddim_sampling_parameters, eta = 0)
+        self.ddim_alphas = ac[self.ddim_timesteps].numpy()
+        self.ddim_alphas_prev = np.asarray([ac[0].item()] + ac[self.ddim_timesteps[:-1]].tolist(), dtype=np.float32)
+        self.ddim_sigmas = np.zeros_like(self.ddim_alphas)
+        self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - ac[self.ddim_timesteps]).numpy()
+
+    # ---- engine plumbing --------------------------------------------------------------------------------
+    @property
+    def engine(self):
+        return self.model.engine
+
+    def _cond(self, inp: Dict) -> "object":
+        g = inp["grounding_input"] if "grounding_input" in inp else self.model.grounding_tokenizer_input.get_null_input()
+        return self.engine.prepare_cond(inp["context"], g)
+
+    def _uncond(self, uc: torch.Tensor):
+        return self.engine.prepare_cond(uc, self.model.grounding_tokenizer_input.get_null_input(batch=uc.shape[0]))
+
+    def _apply_alpha(self, alphas, i):
+        """plms.py:90-94: per-step gate + first-conv swap."""
+        if alphas is not None:
+            self.set_alpha_scale(self.model, alphas[i])
+            if alphas[i] == 0:
+                self.model.restore_first_conv_from_SD()
+            self.engine.sync_fuser_scale_from_modules()
+
+    def _eps(self, x, step: int, cond_pair, n: int, guided: bool, guidance_scale: float):
+        """Guided eps for n trajectories: one batched forward of [cond | uncond] (plms.py:121-127)."""
+        eng = self.engine
+        if guided:
+            xx = torch.cat([x, x], 0)
+            t = torch.full((2 * n,), float(step), device=x.device, dtype=torch.float32)
+            e2 = eng.forward_cond(xx, t, cond_pair, out=eng.buf("smp.eps2", xx.shape, torch.float32))
+            return eng.ops.cfg_combine(e2[:n], e2[n:], guidance_scale, eng.ops.empty(x.shape, torch.float32))
+        t = torch.full((n,), float(step), device=x.device, dtype=torch.float32)
+        return eng.forward_cond(x, t, cond_pair)
+
+    def _plms_step(self, x, old_eps: list, index: int, step: int, step_next: int, cond_pair, n, guided, gs):
+        """p_sample_plms (plms.py:117-167).  Returns (x_prev, e_t)."""
+        ops = self.engine.ops
+        a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
+        s1m = float(self.ddim_sqrt_one_minus_alphas[index])
+        e_t = self._eps(x, step, cond_pair, n, guided, gs)
+        new = ops.empty(x.shape, torch.float32)
+        if len(old_eps) == 0:
+            x_pred = ops.plms_update(x, e_t, [], None, 0, a_t, a_prev, s1m, ops.empty(x.shape, torch.float32))
+            e_next = self._eps(x_pred, step_next, cond_pair, n, guided, gs)
+            ops.plms_update(x, e_t, [], e_next, 1, a_t, a_prev, s1m, new)
+        else:
+            ops.plms_update(x, e_t, old_eps, None, min(len(old_eps), 3) + 1, a_t, a_prev, s1m, new)
+        return new, e_t
+
+    @staticmethod
+    def _push(old_eps: list, e_t):
+        old_eps.append(e_t)
+        if len(old_eps) >= 4:
+            old_eps.pop(0)
+
+
+class PLMSSampler(_PLMSBase):
+    """plms.py:9-167."""
+
+    @torch.no_grad()
+    def sample(self, S, shape, input, uc=None, guidance_scale=1, mask=None, x0=None):
+        self.make_schedule(ddim_num_steps=S)
+        return self.plms_sampling(shape, input, uc, guidance_scale, mask=mask, x0=x0)
+
+    @torch.no_grad()
+    def plms_sampling(self, shape, input, uc=None, guidance_scale=1, mask=None, x0=None):
+        eng = self.engine
+        dev = eng.device
+        b = shape[0]
+        img = input["x"]
+        if img is None:
+            img = torch.randn(shape, device=dev)
+            input["x"] = img
+        img = img.to(dev, torch.float32)
+        guided = uc is not None and guidance_scale != 1
+        cond = self._cond(input)
+        pair = type(cond).cat([cond, self._uncond(uc)]) if guided else cond
+        time_range = np.flip(self.ddim_timesteps)
+        total = self.ddim_timesteps.shape[0]
+        alphas = self.alpha_generator_func(len(time_range)) if self.alpha_generator_func is not None else None
+        old_eps: list = []
+        for i, step in enumerate(time_range):
+            self._apply_alpha(alphas, i)
+            index = total - i - 1
+            step_next = int(time_range[min(i + 1, len(time_range) - 1)])
+            if mask is not None:
+                assert x0 is not None
+                ts = torch.full((b,), int(step), device=dev, dtype=torch.long)
+                img_orig = self.diffusion.q_sample(x0.to(dev), ts)
+                img = img_orig * mask + (1. - mask) * img
+            img, e_t = self._plms_step(img, old_eps, index, int(step), step_next, pair, b, guided, guidance_scale)
+            input["x"] = img
+            input["timesteps"] = torch.full((b,), int(step), device=dev, dtype=torch.long)
+            self._push(old_eps, e_t)
+        return img
+
+
+class PLMSSamplerInst(_PLMSBase):
+    """Multi-instance Sampler, plms_instance.py:7-212."""
+
+    def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None, mis=0.0,
+                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 36):
+        super().__init__(diffusion, model, schedule, alpha_generator_func, set_alpha_scale)
+        self.mis = mis
+        self.crop_and_paste_latents = crop_and_paste_latents      # hard-coded False in the reference (:128)
+        self.shard_across_ranks = shard_across_ranks
+        self.max_units = max_units
+
+    @torch.no_grad()
+    def sample(self, S, shape, input, uc=None, guidance_scale=1, mask=None, x0=None):
+        self.make_schedule(ddim_num_steps=S)
+        return self.plms_sampling(shape, input, uc, guidance_scale, mask=mask, x0=x0)
+
+    # ---- distributed helpers ----------------------------------------------------------------------------
+    def _dist(self):
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.shard_across_ranks is False:
+            on = False
+        return (dist, dist.get_rank(), dist.get_world_size()) if on else (None, 0, 1)
+
+    @torch.no_grad()
+    def plms_sampling(self, shape, input_all, uc=None, guidance_scale=1, mask=None, x0=None):
+        eng = self.engine
+        ops = eng.ops
+        dev = eng.device
+        dist, rank, world = self._dist()
+        B = shape[0]
+        latent_size = shape[2]
+        img = input_all[0]["x"]
+        if img is None:
+            img = torch.randn(shape, device=dev)
+            if dist is not None:
+                dist.broadcast(img, 0)
+            for inp in input_all:
+                inp["x"] = img
+        n_all = len(input_all)
+        guided = uc is not None and guidance_scale != 1
+        time_range = np.flip(self.ddim_timesteps)
+        total = self.ddim_timesteps.shape[0]
+        alphas = self.alpha_generator_func(len(time_range)) if self.alpha_generator_func is not None else None
+        mis_step = int(total * self.mis)
+
+        conds = [self._cond(inp) for inp in input_all]
+        cond_u = self._uncond(uc) if guided else None
+        CondT = type(conds[0])
+
+        # ---------------- phase 1: N+1 independent trajectories per image (plms_instance.py:86-104) ----------
+        # work unit = (instance j, image b), owned by rank (b + j) % world; the owner of image b (rank b % world)
+        # therefore also runs (0, b), whose eps history continues into phase 2.
+        units = [(j, b) for j in range(n_all) for b in range(B) if (b + j) % world == rank]
+        # Reference quirk: restore_first_conv_from_SD is never undone, so if alpha hits 0 inside phase 1 the LATER
+        # instances would run their EARLY steps with the swapped conv.  Only then is the serial order observable;
+        # reproduce it by advancing one instance at a time.
+        serial = alphas is not None and any(alphas[i] == 0 for i in range(mis_step))
+        if serial:
+            chunks = [[u for u in units if u[0] == j] for j in range(n_all)]
+        else:
+            chunks = [units[k:k + self.max_units] for k in range(0, len(units), self.max_units)]
+        x_units: Dict[tuple, torch.Tensor] = {}
+        eps_units: Dict[tuple, list] = {}
+        for chunk in chunks:
+            if not chunk:
+                continue
+            n = len(chunk)
+            x = torch.stack([input_all[j]["x"][b] for (j, b) in chunk]).to(dev, torch.float32)
+            cc = CondT.cat([conds[j].select(torch.tensor([b], device=dev)) for (j, b) in chunk])
+            pair = CondT.cat([cc, CondT.cat([cond_u.select(torch.tensor([b], device=dev)) for (_, b) in chunk])]) \
+                if guided else cc
+            old: list = []
+            for i, step in enumerate(time_range[:mis_step]):
+                self._apply_alpha(alphas, i)
+                index = total - i - 1
+                step_next = int(time_range[min(i + 1, len(time_range) - 1)])
+                x, e_t = self._plms_step(x, old, index, int(step), step_next, pair, n, guided, guidance_scale)
+                self._push(old, e_t)
+            for k, u in enumerate(chunk):
+                x_units[u] = x[k]
+                eps_units[u] = [e[k] for e in old]
+
+        # ---------------- merge (plms_instance.py:128-135) ------------------------------------------------------
+        mine = [b for b in range(B) if b % world == rank]                     # images this rank owns in phase 2
+        if self.crop_and_paste_latents:
+            lat = torch.zeros((n_all, B) + tuple(shape[1:]), device=dev, dtype=torch.float32)
+            for (j, b), xv in x_units.items():
+                lat[j, b] = xv
+            if dist is not None:
+                dist.all_reduce(lat)                                           # disjoint supports: sum == gather
+            boxes = torch.tensor([[int(v * latent_size) for v in inp["grounding_input"]["boxes"][0][0].tolist()]
+                                  for inp in input_all[1:]], dtype=torch.int32, device=dev).reshape(-1, 4)
+            merged = ops.mis_merge(lat, boxes, ops.empty(tuple(shape), torch.float32), 1)
+        else:
+            if dist is None:
+                lat = torch.stack([torch.stack([x_units[(j, b)] for b in range(B)]) for j in range(n_all)])
+                merged = ops.mis_merge(lat.contiguous(), None, ops.empty(tuple(shape), torch.float32), 0)
+            else:
+                part = torch.zeros(tuple(shape), device=dev, dtype=torch.float32)
+                for (j, b), xv in x_units.items():
+                    part[b] += xv
+                dist.all_reduce(part)                                          # the ONE hot-path collective (RCCL)
+                merged = part / float(n_all)
+
+        # ---------------- phase 2: shared trajectory, one per image, sharded over images (:138-156) -------------
+        out = torch.zeros(tuple(shape), device=dev, dtype=torch.float32)
+        if mine:
+            idx = torch.tensor(mine, device=dev)
+            n = len(mine)
+            x = merged[idx].contiguous()
+            old = [torch.stack([eps_units[(0, b)][k] for b in mine]) for k in range(len(eps_units[(0, mine[0])]))] \
+                if mis_step > 0 else []
+            c0 = conds[0].select(idx)
+            pair = CondT.cat([c0, cond_u.select(idx)]) if guided else c0
+            for i, step in enumerate(time_range):
+                if i < mis_step:
+                    continue
+                self._apply_alpha(alphas, i)
+                index = total - i - 1
+                step_next = int(time_range[min(i + 1, len(time_range) - 1)])
+                x, e_t = self._plms_step(x, old, index, int(step), step_next, pair, n, guided, guidance_scale)
+                self._push(old, e_t)
+            out[idx] = x
+        if dist is not None:
+            dist.all_reduce(out)                                               # gather finished images on every rank
+        input_all[0]["x"] = out
+        return out

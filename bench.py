@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""Headline benchmark: InstanceDiffusion Multi-instance Sampler throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric): SD-1.5 InstanceDiffusion UNet (1.228 B parameters, seeded
+synthetic weights -- no checkpoints exist offline), 512x512 images = 64x64 latents, 50 PLMS steps, classifier-free
+guidance 7.5, N=8 box instances, Multi-instance Sampler mis=0.36 (=> 406 UNet forwards per image), alpha schedule
+[0.8, 0, 0.2].  One "step" = one full sampling of the global image batch (images_per_gpu x n_gpus images);
+weak scaling.  Inputs are resident in HBM before the timed region.  VAE decode is outside the path.
+
+Prints ONE JSON line on rank 0 with the driver contract fields plus
+  "roofline"     -- dominant kernel's achieved TFLOP/s (algorithmic flops / HIP-event duration) vs 2.5 PF bf16 MFMA
+  "cpu_baseline" -- the CPU oracle (port of the reference algorithm, fp32) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from functools import partial
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_MFMA_TF = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
+N_INST, S_STEPS, MIS, GUIDANCE, ALPHA_TYPE, LATENT = 8, 50, 0.36, 7.5, [0.8, 0.0, 0.2], 64
+GFLOP_PER_FWD = 1227.3         # reference-algorithmic work per UNet forward per sample at 64x64
+
+
+def n_forwards(n_inst, S, mis):
+    ms = int(S * mis)
+    return 2 * ((n_inst + 1) * (ms + 1) + (S - ms))
+
+
+def build_model(cfg):
+    from instancediffusion_amd import synth
+    from instancediffusion_amd.host.config import unet_kwargs_from_cfg
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    with torch.device("meta"):
+        model = UNetModel(**unet_kwargs_from_cfg(cfg))
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd, assign=True)
+    model.first_conv_sd_override = synth.synth_first_conv_sd()
+    return model.eval(), sd
+
+
+def make_inputs(cfg, n_images, device):
+    """Seeded synthetic C3 inputs: N random boxes, random text embeddings / contexts, shared noise."""
+    from instancediffusion_amd import synth
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    g = torch.Generator().manual_seed(1234)
+    boxes = synth.random_boxes(N_INST, g)
+    gb = synth.make_grounding_batch(n_images, boxes, g)
+    x = torch.randn(n_images, 4, LATENT, LATENT, generator=g)
+    ctx = torch.randn(n_images, 77, 768, generator=g)
+    uc = torch.randn(n_images, 77, 768, generator=g)
+    inst_ctx = [torch.randn(n_images, 77, 768, generator=g) for _ in range(N_INST)]
+    gi = GroundingNetInput()
+
+    def dev(d):
+        return {k: v.to(device) for k, v in d.items()}
+    inputs = [dict(x=x.to(device), timesteps=None, context=ctx.to(device), grounding_input=gi.prepare(dev(gb)))]
+    for i in range(N_INST):
+        inputs.append(dict(x=x.to(device), timesteps=None, context=inst_ctx[i].to(device),
+                           grounding_input=gi.prepare(dev(synth.instance_batch(gb, i)))))
+    gi.prepare(dev(gb))
+    return inputs, uc.to(device), gi, dict(gb=gb, x=x, ctx=ctx)
+
+
+class OpTimer:
+    """Wraps the ops object for ONE eager forward: HIP events (on the launch stream) around every C-ABI call."""
+
+    def __init__(self, ops):
+        self.ops, self.records = ops, []
+
+    def __getattr__(self, name):
+        fn = getattr(self.ops, name)
+        if name not in ("gemm", "conv3x3", "attention", "groupnorm", "layernorm", "scaleu_concat", "conv_in",
+                        "timestep_embedding"):
+            return fn
+
+        def timed(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            self.records.append((name, self._work(name, a, k), s, e))
+            return r
+        return timed
+
+    @staticmethod
+    def _work(name, a, k):
+        if name == "gemm":
+            A, W, out = a[0], a[1], a[2]
+            batch = out.shape[0] if out.dim() == 3 else 1
+            return 2.0 * batch * A.shape[-2] * W.shape[-2] * A.shape[-1]
+        if name == "conv3x3":
+            x, w, out = a[0], a[1], a[2]
+            npix = out.numel() // out.shape[1] if k.get("n_valid") else out.numel() // out.shape[-1]
+            return 2.0 * npix * w.shape[0] * w.shape[1]
+        if name == "attention":
+            q, n0 = a[0], a[3]
+            return 4.0 * q.shape[0] * q.shape[1] * (n0 + k.get("n1", 0)) * q.shape[2]
+        return 0.0
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, work, s, e in self.records:
+            d = agg.setdefault(name, dict(calls=0, ms=0.0, flops=0.0))
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += work
+        return agg
+
+
+def measure_roofline(engine, batch):
+    """One instrumented eager forward at the phase-1 batch: per-kernel-family durations from HIP events."""
+    dev = engine.device
+    from instancediffusion_amd.engine import Cond
+    cond = engine._slots[batch]
+    x = torch.randn(batch, 4, LATENT, LATENT, device=dev)
+    t = torch.full((batch,), 500.0, device=dev)
+    eps = torch.empty(batch, 4, LATENT, LATENT, device=dev)
+    real = engine.ops
+    for _ in range(2):                                   # 1 warm + 1 measured
+        timer = OpTimer(real)
+        engine.ops = timer
+        try:
+            engine._forward_ops(x, t, cond, eps, True)
+        finally:
+            engine.ops = real
+    agg = timer.summary()
+    total_ms = sum(d["ms"] for d in agg.values())
+    dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    name, d = dom
+    kern = {"conv3x3": "gemm_kernel<.., CONV=true> (implicit-GEMM 3x3 conv)", "gemm": "gemm_kernel<.., CONV=false>",
+            "attention": "attn_kernel"}.get(name, name)
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    return dict(bound="mfma", kernel=kern, achieved=round(achieved, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
+                frac=round(achieved / PEAK_MFMA_TF, 4), traffic=None,
+                launches_per_forward=d["calls"], avg_launch_us=round(d["ms"] * 1e3 / d["calls"], 2),
+                algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3), measured_at_batch=batch,
+                forward_breakdown_ms={k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+                forward_total_ms=round(total_ms, 3))
+
+
+def cpu_baseline(cfg, sd, host_inputs, budget_s=25.0):
+    """The CPU oracle (fp32 port of the reference algorithm) on this host's cores, bounded sample."""
+    from oracle import ref_cpu
+    torch.set_num_threads(os.cpu_count() or 1)
+    gb, x, ctx = host_inputs["gb"], host_inputs["x"][:1], host_inputs["ctx"][:1]
+    g = ref_cpu.prepare_grounding({k: v[:1] for k, v in gb.items()})
+    t = torch.full((1,), 981, dtype=torch.long)
+    with torch.no_grad():
+        objs, _ = ref_cpu.unifusion(sd, cfg, g)
+        ref_cpu.unet_forward(sd, cfg, x, t, ctx, objs)              # warm-up
+        times = []
+        t_begin = time.time()
+        while len(times) < 5 and (time.time() - t_begin) < budget_s:
+            t0 = time.time()
+            ref_cpu.unet_forward(sd, cfg, x, t, ctx, objs)
+            times.append(time.time() - t0)
+    t_fwd = sorted(times)[len(times) // 2]
+    nf = n_forwards(N_INST, S_STEPS, MIS)
+    return dict(value=1.0 / (nf * t_fwd), unit="img/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(times)} timed full-size UNet forwards (B=1, 64x64 latent, fp32, median {t_fwd:.3f} s) "
+                       f"x {nf} forwards/image (extrapolated)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" == RCCL on ROCm
+
+    from oracle import ref_cpu                                    # only for DEFAULT_CFG + the cpu_baseline leg
+    from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.diffusion import LatentDiffusion
+    from instancediffusion_amd.host.samplers import PLMSSamplerInst
+    cfg = dict(ref_cpu.DEFAULT_CFG)
+    model, sd = build_model(cfg)
+    n_images = args.images_per_gpu * world
+    inputs, uc, gi, host_inputs = make_inputs(cfg, n_images, dev)
+    model.grounding_tokenizer_input = gi
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    _ = model.engine                                              # pack weights into HBM (bf16 GEMM images)
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=ALPHA_TYPE),
+                              set_alpha_scale=set_alpha_scale, mis=MIS)
+    shape = (n_images, 4, LATENT, LATENT)
+
+    def one_step():
+        # NOTE (reference quirk kept): the first-conv swap at alpha == 0 is never undone (openaimodel.py:469-480),
+        # so every image batch after the first starts with the SD first conv -- same arithmetic cost either way.
+        ins = [dict(d) for d in inputs]
+        return sampler.sample(S=S_STEPS, shape=shape, input=ins, uc=uc, guidance_scale=GUIDANCE)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / max(args.steps, 1) * 1e3
+        value = n_images * args.steps / elapsed
+        nf = n_forwards(N_INST, S_STEPS, MIS)
+        line = {
+            "metric": "images/sec at 512x512, 50 PLMS steps, N=8 instances (Multi-instance Sampler)",
+            "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C3: SD-1.5 InstanceDiffusion UNet (1.228B params, seeded random weights), 64x64 latent "
+                                   "(512x512), 50 PLMS steps, CFG 7.5, N=8 boxes, MIS 0.36, alpha [0.8,0,0.2]",
+                       "images_per_gpu": args.images_per_gpu, "global_images_per_step": n_images,
+                       "unet_forwards_per_image": nf, "parallelism": f"mis-unit-shard x{world} + image-shard x{world}"},
+            "whole_step_algorithmic_tflops_per_gpu": round(value * nf * GFLOP_PER_FWD / 1e3 / world, 1),
+            "whole_step_frac_of_mfma_peak": round(value * nf * GFLOP_PER_FWD / 1e3 / world / PEAK_MFMA_TF, 4),
+        }
+        if not args.no_roofline:
+            phase1_batch = max(model.engine._slots.keys())
+            line["roofline"] = measure_roofline(model.engine, phase1_batch)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, host_inputs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

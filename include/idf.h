@@ -55,6 +55,8 @@ typedef struct {
   int rows_per_batch;                 /* ROWBIAS: rowbias row = m / rows_per_batch                          */
   int batch; long long strideA, strideW, strideO, strideR;
   int epi; int dtype;
+  void* ws; long long ws_bytes;       /* optional fp32 split-K workspace (NULL = never split); used when the tile   */
+                                      /* grid cannot fill 256 CUs: slices write partial slabs, a reducer applies epi */
 } idf_gemm_args;
 int idf_gemm(const idf_gemm_args* a, void* stream);
 
@@ -71,6 +73,7 @@ typedef struct {
   int ldx, ldo, ldr, ld_rowbias;
   int n_valid;      /* OUT_NCHW: number of real output channels (<= Cout) */
   int epi; int dtype;
+  void* ws; long long ws_bytes;       /* optional fp32 split-K workspace, as in idf_gemm_args */
 } idf_conv3x3_args;
 int idf_conv3x3(const idf_conv3x3_args* a, void* stream);
 

@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("lda", ci), ("ldw", ci), ("ldo", ci), ("ldr", ci), ("ld_rowbias", ci),
                 ("rows_per_batch", ci),
                 ("batch", ci), ("strideA", ll), ("strideW", ll), ("strideO", ll), ("strideR", ll),
-                ("epi", ci), ("dtype", ci)]
+                ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll)]
 
 
 class ConvArgs(C.Structure):
@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
                 ("B", ci), ("Hin", ci), ("Win", ci), ("Cin", ci), ("Cout", ci),
                 ("stride", ci), ("upsample", ci),
                 ("ldx", ci), ("ldo", ci), ("ldr", ci), ("ld_rowbias", ci),
-                ("n_valid", ci), ("epi", ci), ("dtype", ci)]
+                ("n_valid", ci), ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll)]
 
 
 class AttnArgs(C.Structure):

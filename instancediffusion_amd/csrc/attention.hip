@@ -66,38 +66,53 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   const int T1 = (p.n[1] + KVT - 1) / KVT;
   const int T = T0 + T1;
 
-  // ---- staging registers (prefetch of the next tile)
+  // ---- staging roles (tile-invariant): thread -> K chunks (row, 16-B chunk) and V^T chunks (e row, 8-kv chunk)
+  int k_lds[KCH_MAX], k_row[KCH_MAX], k_col[KCH_MAX];
+#pragma unroll
+  for (int i = 0; i < KCH_MAX; ++i) {
+    const int id = tid + i * 256;
+    const int row = id / dch, ch = id - row * dch;
+    k_row[i] = row < KVT ? row : -1;
+    k_col[i] = ch * 8;
+    k_lds[i] = row * KSTR + ch * 8;
+  }
+  int v_lds[VCH_MAX], v_row[VCH_MAX];
+  const int v_ch8 = (tid & 7) * 8;
+#pragma unroll
+  for (int i = 0; i < VCH_MAX; ++i) {
+    const int row = (tid + i * 256) >> 3;
+    v_row[i] = row < d ? row : -1;
+    v_lds[i] = row * VSTR + v_ch8;
+  }
+
   u32x4 kreg[KCH_MAX], vreg[VCH_MAX];
   auto prefetch = [&](int t) {
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
+    const int ldk = p.ldk[seg], ldv = p.ldv[seg];
     const unsigned short* kb = p.k[seg] + (size_t)b * p.sK[seg] + h * d;
-    const unsigned short* vb = p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * d) * p.ldv[seg] + kv0;
+    const unsigned short* vb = p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * d) * ldv + kv0 + v_ch8;
 #pragma unroll
     for (int i = 0; i < KCH_MAX; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / dch, ch = id - row * dch;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < KVT) {
-        const int kr = min(kv0 + row, n - 1);
-        v = *reinterpret_cast<const u32x4*>(kb + (size_t)kr * p.ldk[seg] + ch * 8);
+      if (k_row[i] >= 0) {
+        const int kr = min(kv0 + k_row[i], n - 1);
+        v = *reinterpret_cast<const u32x4*>(kb + (size_t)kr * ldk + k_col[i]);
       }
       kreg[i] = v;
     }
+    const bool tail = (n - kv0) < KVT;               // wave-uniform
 #pragma unroll
     for (int i = 0; i < VCH_MAX; ++i) {
-      const int id = tid + i * 256;
-      const int row = id >> 3, ch = id & 7;       // row = e (0..d-1), 8 chunks of 8 kv
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < d) {
-        v = *reinterpret_cast<const u32x4*>(vb + (size_t)row * p.ldv[seg] + ch * 8);
-        const int valid = n - (kv0 + ch * 8);      // number of valid kv in this chunk (may be <=0 or >=8)
-        if (valid < 8) {                           // zero the invalid tail (keeps 0 * garbage out of P.V)
+      if (v_row[i] >= 0) {
+        v = *reinterpret_cast<const u32x4*>(vb + (size_t)v_row[i] * ldv);
+        if (tail) {                                   // zero kv >= n (keeps 0 * garbage out of P.V)
+          const int valid = n - (kv0 + v_ch8);
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
-            unsigned m = 0xffffffffu;
-            if (valid <= 2 * w) m = 0u; else if (valid == 2 * w + 1) m = 0x0000ffffu;
+            const unsigned m = (valid >= 2 * w + 2) ? 0xffffffffu : ((valid == 2 * w + 1) ? 0x0000ffffu : 0u);
             v[w] &= m;
           }
         }
@@ -107,22 +122,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < KCH_MAX; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / dch, ch = id - row * dch;
-      if (row < KVT) *reinterpret_cast<u32x4*>(Kl + row * KSTR + ch * 8) = kreg[i];
-    }
+    for (int i = 0; i < KCH_MAX; ++i)
+      if (k_row[i] >= 0) *reinterpret_cast<u32x4*>(Kl + k_lds[i]) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < VCH_MAX; ++i) {
-      const int id = tid + i * 256;
-      const int row = id >> 3, ch = id & 7;
-      if (row < d) {
-        // VSTR*2 = 136 B is only 8-B aligned: two 8-B stores
+    for (int i = 0; i < VCH_MAX; ++i)
+      if (v_row[i] >= 0) {
+        // VSTR*2 = 136 B rows are only 8-B aligned: two 8-B stores
         u32x2 lo = {vreg[i][0], vreg[i][1]}, hi2 = {vreg[i][2], vreg[i][3]};
-        *reinterpret_cast<u32x2*>(Vl + row * VSTR + ch * 8) = lo;
-        *reinterpret_cast<u32x2*>(Vl + row * VSTR + ch * 8 + 4) = hi2;
+        *reinterpret_cast<u32x2*>(Vl + v_lds[i]) = lo;
+        *reinterpret_cast<u32x2*>(Vl + v_lds[i] + 4) = hi2;
       }
-    }
   };
 
   f32x16 o[NMT];
@@ -148,11 +157,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     f32x16 s[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[st][r] = 0.0f;
       const unsigned short* kf = Kl + (st * 32 + l31) * KSTR + hi * 8;
+      {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u32x4 a = *reinterpret_cast<const u32x4*>(kf);
+        s[st] = Elem<DT>::mfma32(a, qf[0], zero);
+      }
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
+      for (int ks = 1; ks < NKS; ++ks) {
         u32x4 a = *reinterpret_cast<const u32x4*>(kf + ks * 16);
         s[st] = Elem<DT>::mfma32(a, qf[ks], s[st]);
       }
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (kv >= nvalid) s[st][r] = -INFINITY;
+          s[st][r] = (kv >= nvalid) ? -INFINITY : s[st][r];
         }
     }
     float mx = s[0][0];

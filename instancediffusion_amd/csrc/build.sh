@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libidf_gfx950.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 OBJS=""
 for f in gemm_conv attention norms scaleu misc; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/idf.h -nt build/$f.o ]; then

@@ -10,6 +10,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 #define WAVE 64
 
@@ -18,11 +21,11 @@ template <int DT> struct Elem;   // DT = IDF_BF16 / IDF_F16
 
 template <> struct Elem<IDF_BF16> {
   static __device__ __forceinline__ float to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
-  static __device__ __forceinline__ unsigned short from_f32(float f) {   // round-to-nearest-even
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+  // hardware round-to-nearest-even conversions (gfx950 v_cvt_pk_bf16_f32)
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
   }
   static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -32,14 +35,16 @@ template <> struct Elem<IDF_BF16> {
 template <> struct Elem<IDF_F16> {
   static __device__ __forceinline__ float to_f32(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
   static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+  static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  }
   static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
 
-template <int DT> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)Elem<DT>::from_f32(lo) | ((unsigned)Elem<DT>::from_f32(hi) << 16);
-}
+template <int DT> __device__ __forceinline__ unsigned pack2(float lo, float hi) { return Elem<DT>::pack(lo, hi); }
 template <int DT> __device__ __forceinline__ void unpack8(u32x4 v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

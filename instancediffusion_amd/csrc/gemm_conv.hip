@@ -20,10 +20,83 @@ struct CoreParams {
   const float* bias; const unsigned short* rowbias; int ld_rowbias; int rows_per_batch;
   const unsigned short* res; int ldr; long long strideR;
   const float* gate; int epi; int n_valid;
+  float* ws; size_t ws_bytes; int splitk; int kt_per_slice;   // split-K: fp32 partial slabs ws[slice][M][N]
 };
 
 constexpr int BK = 64;
 constexpr int LSTR = 72;   // LDS row stride in elements (144 B)
+
+// epilogue for 4 consecutive output columns n..n+3 of row m (shared by the main kernel and the split-K reducer)
+template <int DT>
+__device__ __forceinline__ void epilogue4(const CoreParams& p, int bz, int m, int n, float* v, float gate) {
+  const int epi = p.epi;
+  const bool full = (n + 3 < p.N);
+  if (epi & IDF_EPI_BIAS) {
+    if (full) {                                       // n % 4 == 0 and bias is 16-B aligned: one 16-B load
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bv[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+    }
+  }
+  if (epi & IDF_EPI_ROWBIAS) {
+    const unsigned short* rb = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n;
+    if (full && ((p.ld_rowbias & 3) == 0)) {
+      const u32x2 r2 = *reinterpret_cast<const u32x2*>(rb);
+      v[0] += Elem<DT>::to_f32((unsigned short)(r2[0] & 0xffffu)); v[1] += Elem<DT>::to_f32((unsigned short)(r2[0] >> 16));
+      v[2] += Elem<DT>::to_f32((unsigned short)(r2[1] & 0xffffu)); v[3] += Elem<DT>::to_f32((unsigned short)(r2[1] >> 16));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
+    }
+  }
+  if (epi & IDF_EPI_SILU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+  }
+  if (epi & IDF_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+  }
+  if (epi & IDF_EPI_RES) {
+    const unsigned short* rr = p.res + (size_t)bz * p.strideR + (size_t)m * p.ldr + n;
+    const float gm = (epi & IDF_EPI_GATE) ? gate : 1.0f;
+    if (full && ((p.ldr & 3) == 0)) {
+      const u32x2 r2 = *reinterpret_cast<const u32x2*>(rr);
+      v[0] = fmaf(gm, v[0], Elem<DT>::to_f32((unsigned short)(r2[0] & 0xffffu)));
+      v[1] = fmaf(gm, v[1], Elem<DT>::to_f32((unsigned short)(r2[0] >> 16)));
+      v[2] = fmaf(gm, v[2], Elem<DT>::to_f32((unsigned short)(r2[1] & 0xffffu)));
+      v[3] = fmaf(gm, v[3], Elem<DT>::to_f32((unsigned short)(r2[1] >> 16)));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) v[e] = fmaf(gm, v[e], Elem<DT>::to_f32(rr[e]));
+    }
+  }
+  if (epi & IDF_EPI_OUT_NCHW) {
+    const int hw = p.Ho * p.Wo;
+    const int bb = m / hw, rem = m - bb * hw;
+    float* o = reinterpret_cast<float*>(p.out);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.n_valid) o[((size_t)bb * p.n_valid + (n + e)) * hw + rem] = v[e];
+  } else if (epi & IDF_EPI_OUT_F32) {
+    float* o = reinterpret_cast<float*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (full || n + e < p.N) o[e] = v[e];
+  } else {
+    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+    if (full && ((p.ldo & 3) == 0)) {
+      u32x2 pk = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(o) = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
+    }
+  }
+}
 
 template <int DT, int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
@@ -38,8 +111,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int bz = blockIdx.z;
+  // XCD-aware tile order: workgroup L runs on XCD L % 8 (8 private L2s); give each XCD a CONTIGUOUS chunk of the
+  // n-fastest tile list so the n-tiles that share one activation m-tile hit the same L2 (bijective for any count).
+  int tile;
+  {
+    const int T = gridDim.x, L = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = L & 7, i = L >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m_tile = tile / tiles_n;
+  const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
+  const int bz = (p.splitk > 1) ? 0 : blockIdx.z;            // split-K launches are never batched
 
   const unsigned short* Wb = p.W + (size_t)bz * p.strideW;
   const unsigned short* Ab = p.A + (size_t)bz * p.strideA;
@@ -69,13 +152,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
       arow[i] = Ab + (size_t)m * p.lda + c * 8;
     }
   }
-  const int nk = p.K / BK;
+  const int nk_all = p.K / BK;
+  const int kt_begin = (p.splitk > 1) ? blockIdx.z * p.kt_per_slice : 0;
+  const int nk = (p.splitk > 1) ? min(p.kt_per_slice, nk_all - kt_begin) : nk_all;   // K-tiles of this block
   int tap = 0, ci0 = 0;                                // conv: K-tile -> (3x3 tap, channel offset)
+  if (CONV) { tap = (kt_begin * BK) / p.Cin; ci0 = kt_begin * BK - tap * p.Cin; }
 
   u32x4 ra[AR], rw[WR];
   auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < WR; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt * BK);
+    for (int i = 0; i < WR; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)(kt_begin + kt) * BK);
     if (CONV) {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
@@ -92,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
       if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
     } else {
 #pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const u32x4*>(arow[i] + (size_t)kt * BK);
+      for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const u32x4*>(arow[i] + (size_t)(kt_begin + kt) * BK);
     }
   };
   auto store_tile = [&](int buf) {
@@ -141,7 +227,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
   // ---- epilogue.  acc[a][b][r]: n = nb + (r&3) + 8*(r>>2) + 4*hi ; m = mb + l31
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
-  const unsigned short* resb = p.res ? p.res + (size_t)bz * p.strideR : nullptr;
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
     const int m = m0 + wm * WM + b * 32 + l31;
@@ -181,58 +266,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e];
-        const bool full = (n + 3 < p.N);
-        if (epi & IDF_EPI_BIAS) {
+        if (p.splitk > 1) {
+          float* o = p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + n;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (full || n + e < p.N) v[e] += p.bias[n + e];
-        }
-        if (epi & IDF_EPI_ROWBIAS) {
-          const unsigned short* rb = p.rowbias + (size_t)brow * p.ld_rowbias + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (full || n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
-        }
-        if (epi & IDF_EPI_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-        }
-        if (epi & IDF_EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-        }
-        if (epi & IDF_EPI_RES) {
-          const unsigned short* rr = resb + (size_t)m * p.ldr + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (full || n + e < p.N) {
-              float rv = Elem<DT>::to_f32(rr[e]);
-              v[e] = (epi & IDF_EPI_GATE) ? (rv + gate * v[e]) : (rv + v[e]);
-            }
-          }
-        }
-        if (epi & IDF_EPI_OUT_NCHW) {
-          const int hw = p.Ho * p.Wo;
-          const int bb = m / hw, rem = m - bb * hw;
-          float* o = reinterpret_cast<float*>(p.out);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.n_valid) o[((size_t)bb * p.n_valid + (n + e)) * hw + rem] = v[e];
-        } else if (epi & IDF_EPI_OUT_F32) {
-          float* o = reinterpret_cast<float*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (full || n + e < p.N) o[e] = v[e];
+          for (int e = 0; e < 4; ++e) if (n + e < p.N) o[e] = v[e];
         } else {
-          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
-          if (full && ((p.ldo & 3) == 0)) {
-            u32x2 pk = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(o) = pk;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
-          }
+          epilogue4<DT>(p, bz, m, n, v, gate);
         }
       }
     }
   }
+}
+
+// out = epi(sum over K-slices) for split-K launches: one thread per 4 consecutive columns of one row
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) {
+  const int n4 = (p.N + 3) / 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)p.M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splitk; ++s) {
+    const float* w = p.ws + ((size_t)s * p.M + m) * p.N + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += w[e];
+  }
+  const float gate = (p.epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+  epilogue4<DT>(p, 0, m, n, v, gate);
 }
 
 template <int DT, int BM, int BN, int WM, int WN, bool CONV>
@@ -245,8 +305,27 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  CoreParams q = p;
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  const int nk = p.K / BK;
+  q.splitk = 1; q.kt_per_slice = nk;
+  // split-K when the tile grid cannot fill the 256 CUs (small-spatial / small-batch layers with long K)
+  if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles < 192 && nk >= 8) {
+    int want = (512 + tiles - 1) / tiles;
+    if (want > nk / 4) want = nk / 4;
+    if (want > 64) want = 64;
+    while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > p.ws_bytes) --want;
+    if (want > 1) {
+      q.kt_per_slice = (nk + want - 1) / want;
+      q.splitk = (nk + q.kt_per_slice - 1) / q.kt_per_slice;
+    }
+  }
+  dim3 grid(tiles, 1, q.splitk > 1 ? q.splitk : batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, q);
+  if (q.splitk > 1) {
+    const size_t n4 = (size_t)q.M * ((q.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q);
+  }
   return idf_launch_status();
 }
 
@@ -278,6 +357,7 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   p.rows_per_batch = a->rows_per_batch;
   p.res = (const unsigned short*)a->res; p.ldr = a->ldr; p.strideR = a->strideR;
   p.gate = a->gate; p.epi = a->epi; p.n_valid = a->N;
+  p.ws = (float*)a->ws; p.ws_bytes = a->ws ? (size_t)a->ws_bytes : 0;
   const int batch = a->batch > 0 ? a->batch : 1;
   hipStream_t s = (hipStream_t)stream;
   if (a->dtype == IDF_BF16) return launch<IDF_BF16, false>(p, batch, s);
@@ -305,6 +385,7 @@ extern "C" int idf_conv3x3(const idf_conv3x3_args* a, void* stream) {
   p.rows_per_batch = p.Ho * p.Wo;
   p.res = (const unsigned short*)a->res; p.ldr = a->ldr; p.strideR = 0;
   p.gate = nullptr; p.epi = a->epi; p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout;
+  p.ws = (float*)a->ws; p.ws_bytes = a->ws ? (size_t)a->ws_bytes : 0;
   if ((a->epi & IDF_EPI_ROWBIAS) && !a->rowbias) return IDF_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (a->dtype == IDF_BF16) return launch<IDF_BF16, true>(p, 1, s);

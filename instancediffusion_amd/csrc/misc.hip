@@ -45,38 +45,53 @@ __global__ void unifusion_embed_kernel(const float* __restrict__ text, const flo
   out[i] = Elem<DT>::from_f32(v);
 }
 
-// first conv (Cin = 4): NCHW fp32 latent -> NHWC 16-bit.  One thread per (pixel, 8 output channels).
+// first conv (Cin = 4): NCHW fp32 latent -> NHWC 16-bit.  One thread per (pixel, 8 output channels); the fp32 weights
+// (Cout*Cin*9 floats, 46 KB for 320x4) are staged once per workgroup in LDS as [tap][ci][co] so a thread's 8 output
+// channels read two 16-B LDS vectors per (tap, ci).  One workgroup = 256/cg... pixels x all channel groups.
 template <int DT>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, unsigned short* __restrict__ out,
-                                                     int B, int Cin, int H, int W, int Cout) {
+                                                     int B, int Cin, int H, int W, int Cout, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [9*Cin][Cout]
+  const int K = 9 * Cin;
+  for (int i = threadIdx.x; i < K * Cout; i += 256) {
+    const int co = i / K, k = i - co * K;                        // w is [co][ci][ky][kx]; k = ci*9 + tap
+    const int ci = k / 9, tap = k - ci * 9;
+    wl[(tap * Cin + ci) * Cout + co] = w[i];
+  }
+  __syncthreads();
   const int cg = Cout >> 3;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)B * H * W * cg) return;
-  const int g = (int)(i % cg);
-  const size_t pix = i / cg;
-  const int b = (int)(pix / (H * W)), r = (int)(pix - (size_t)b * H * W);
-  const int y = r / W, xx = r - y * W;
-  float acc[8];
+  const size_t npix = (size_t)B * H * W;
+  const size_t pix0 = (size_t)blockIdx.x * pix_per_block;
+  for (int it = threadIdx.x; it < pix_per_block * cg; it += 256) {
+    const int g = it % cg;
+    const size_t pix = pix0 + it / cg;
+    if (pix >= npix) break;
+    const int b = (int)(pix / (H * W)), r = (int)(pix - (size_t)b * H * W);
+    const int y = r / W, xx = r - y * W;
+    float acc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
-  for (int ci = 0; ci < Cin; ++ci) {
-    const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+    for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + ((size_t)b * Cin + ci) * H * W;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = y + ky - 1;
-      if (yy < 0 || yy >= H) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= H) continue;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xc = xx + kx - 1;
-        if (xc < 0 || xc >= W) continue;
-        const float xv = xp[yy * W + xc];
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xc = xx + kx - 1;
+          if (xc < 0 || xc >= W) continue;
+          const float xv = xp[yy * W + xc];
+          const float* wp = wl + ((ky * 3 + kx) * Cin + ci) * Cout + g * 8;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, w[(((size_t)(g * 8 + j) * Cin + ci) * 3 + ky) * 3 + kx], acc[j]);
+          for (int j = 0; j < 4; ++j) { acc[j] = fmaf(xv, w0[j], acc[j]); acc[j + 4] = fmaf(xv, w1[j], acc[j + 4]); }
+        }
       }
     }
+    *reinterpret_cast<u32x4*>(out + pix * Cout + g * 8) = pack8<DT>(acc);
   }
-  *reinterpret_cast<u32x4*>(out + pix * Cout + g * 8) = pack8<DT>(acc);
 }
 
 __global__ void cfg_kernel(const float* __restrict__ ec, const float* __restrict__ eu, float g, float* __restrict__ et, long long n) {
@@ -169,9 +184,13 @@ extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bia
   if (!x_nchw || !w || !bias || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8)) return IDF_E_ARG;
   if (!aligned16(out)) return IDF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  const long long n = (long long)B * H * W * (Cout / 8);
-  if (dtype == IDF_BF16) hipLaunchKernelGGL(conv_in_kernel<IDF_BF16>, grid1d(n), dim3(256), 0, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout);
-  else if (dtype == IDF_F16) hipLaunchKernelGGL(conv_in_kernel<IDF_F16>, grid1d(n), dim3(256), 0, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout);
+  const size_t smem = (size_t)9 * Cin * Cout * sizeof(float);
+  if (smem > 64 * 1024) return IDF_E_UNSUPPORTED;
+  const int ppb = 64;                                           // pixels per workgroup
+  const long long npix = (long long)B * H * W;
+  dim3 grid((unsigned)((npix + ppb - 1) / ppb));
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(conv_in_kernel<IDF_BF16>, grid, dim3(256), smem, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout, ppb);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(conv_in_kernel<IDF_F16>, grid, dim3(256), smem, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout, ppb);
   else return IDF_E_UNSUPPORTED;
   return idf_launch_status();
 }

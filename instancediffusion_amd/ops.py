@@ -50,6 +50,11 @@ class HipOps:
             self._ws[key] = w
         return w
 
+    SPLITK_WS_BYTES = 256 << 20
+
+    def _splitk_ws(self) -> torch.Tensor:
+        return self._workspace("splitk", self.SPLITK_WS_BYTES // 4)
+
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
@@ -101,7 +106,7 @@ class HipOps:
             M=M, N=N, K=K, lda=lda, ldw=ldw, ldo=ldo, ldr=ldr,
             ld_rowbias=0 if rowbias is None else rowbias.stride(-2), rows_per_batch=rows_per_batch,
             batch=out.shape[0] if batched else 1, strideA=sA, strideW=sW, strideO=sO, strideR=sR,
-            epi=epi, dtype=self.dt)
+            epi=epi, dtype=self.dt, ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES)
         _lib.check(self.lib.idf_gemm(C.byref(args), self._stream()), "idf_gemm")
         return out
 
@@ -131,7 +136,8 @@ class HipOps:
             res=None if res is None else res.data_ptr(),
             B=B, Hin=H, Win=W_, Cin=Cin, Cout=Cout, stride=stride, upsample=upsample,
             ldx=x.stride(2), ldo=ldo, ldr=0 if res is None else res.stride(2),
-            ld_rowbias=0 if rowbias is None else rowbias.stride(-2), n_valid=n_valid, epi=epi, dtype=self.dt)
+            ld_rowbias=0 if rowbias is None else rowbias.stride(-2), n_valid=n_valid, epi=epi, dtype=self.dt,
+            ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES)
         _lib.check(self.lib.idf_conv3x3(C.byref(args), self._stream()), "idf_conv3x3")
         return out
 

@@ -109,6 +109,21 @@ int idf_groupnorm(const void* x, void* out, const float* gamma, const float* bet
 int idf_layernorm(const void* x, int ldx, void* out, int ldo, const float* gamma, const float* beta,
                   int M, int C, float eps, int dtype, void* stream);
 
+/* LayerNorm over C of an NHWC image whose output is written in 2x2/stride-2 PATCH order (row = (b, y/2, x/2),
+ * column block ((y&1)*2+(x&1))*C, ld = ldo >= 4C): LayerNorm(channels_first) + the im2col of the 2x2 stride-2
+ * downsample conv of ConvNeXt (convnext.py:78-82) in one pass, so that conv is a plain idf_gemm.               */
+int idf_layernorm_patch2(const void* x, void* out, int ldo, const float* gamma, const float* beta,
+                         int B, int H, int W, int C, float eps, int dtype, void* stream);
+
+/* ---- UniFusion instance-mask tokenizer pieces (text_grounding_net.py:226-231; convnext.py:15-110), once per
+ * conditioning.  idf_seg_in_conv: Conv2d(Cin<=32 -> 3, 3x3, pad 1) on fp32 [B,Cin,S,S], output written as the stem's
+ * 4x4/stride-4 patch matrix out[b*(S/4)^2 + py*(S/4) + px][c*16 + ky*4 + kx] (16-bit, ld = ldo >= 48).
+ * idf_dwconv7x7: depthwise 7x7 pad 3 on NHWC 16-bit; weights fp32 TAP-MAJOR [49][C].                             */
+int idf_seg_in_conv(const float* segs, const float* w /*[3][Cin][3][3]*/, const float* bias, void* out,
+                    int B, int Cin, int S, int ldo, int dtype, void* stream);
+int idf_dwconv7x7(const void* x, const float* w_tap_major, const float* bias, void* out, int B, int H, int W, int C,
+                  int dtype, void* stream);
+
 /* ---- ScaleU (openaimodel.py:519-539 + Fourier_filter :25-48) ---------------------------------------------
  * out[b,p,0:Ch] = h * hscale[c];  out[b,p,Ch:Ch+Cs] = skip + sm1[0] * lowfreq4(skip)   (exact 4-bin identity)
  * hscale = tanh(scaleu_b)+1 (f32 [Ch]); sm1 = tanh(scaleu_s) (f32 scalar on device).

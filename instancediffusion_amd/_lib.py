@@ -54,6 +54,9 @@ SYMBOLS = {
     "idf_groupnorm_ws_floats": (ll, [ci, ci]),
     "idf_groupnorm": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]),
     "idf_layernorm": (ci, [vp, ci, vp, ci, vp, vp, ci, ci, cf, ci, vp]),
+    "idf_layernorm_patch2": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, cf, ci, vp]),
+    "idf_seg_in_conv": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "idf_dwconv7x7": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "idf_scaleu_concat": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "idf_timestep_embedding": (ci, [vp, vp, ci, ci, ci, vp]),
     "idf_unifusion_embed": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),

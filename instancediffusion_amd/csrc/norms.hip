@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
 template <int DT>
 __global__ __launch_bounds__(256) void ln_kernel(const unsigned short* __restrict__ x, int ldx, unsigned short* __restrict__ out,
                                                 int ldo, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                int M, int C, float eps) {
+                                                int M, int C, float eps, int pH, int pW) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -150,7 +150,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const unsigned short* __restric
     }
   }
   const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
-  unsigned short* orow = out + (size_t)row * ldo;
+  // output row: identity, or (pW > 0) the 2x2/stride-2 patch gather of an [B, pH, pW, C] image:
+  // pixel (b, y, x) -> row (b, y/2, x/2), column block ((y&1)*2 + (x&1)) * C   (ConvNeXt downsample, convnext.py:78-82)
+  size_t orow_idx = (size_t)row;
+  int ocol = 0;
+  if (pW > 0) {
+    const int hw = pH * pW;
+    const int b = row / hw, r = row - b * hw;
+    const int y = r / pW, x2 = r - y * pW;
+    orow_idx = ((size_t)b * (pH >> 1) + (y >> 1)) * (pW >> 1) + (x2 >> 1);
+    ocol = ((y & 1) * 2 + (x2 & 1)) * C;
+  }
+  unsigned short* orow = out + orow_idx * ldo + ocol;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int cc = lane + 64 * i;
@@ -212,9 +223,26 @@ extern "C" int idf_layernorm(const void* x, int ldx, void* out, int ldo, const f
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((M + 3) / 4);
   if (dtype == IDF_BF16)
-    hipLaunchKernelGGL(ln_kernel<IDF_BF16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, (unsigned short*)out, ldo, gamma, beta, M, C, eps);
+    hipLaunchKernelGGL(ln_kernel<IDF_BF16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, (unsigned short*)out, ldo, gamma, beta, M, C, eps, 0, 0);
   else if (dtype == IDF_F16)
-    hipLaunchKernelGGL(ln_kernel<IDF_F16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, (unsigned short*)out, ldo, gamma, beta, M, C, eps);
+    hipLaunchKernelGGL(ln_kernel<IDF_F16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, (unsigned short*)out, ldo, gamma, beta, M, C, eps, 0, 0);
+  else
+    return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
+extern "C" int idf_layernorm_patch2(const void* x, void* out, int ldo, const float* gamma, const float* beta,
+                                    int B, int H, int W, int C, float eps, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta) return IDF_E_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8) || C > 1536 || ldo < 4 * C) return IDF_E_ARG;
+  if ((ldo % 8) || !aligned16(x) || !aligned16(out) || !aligned16(gamma) || !aligned16(beta)) return IDF_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int M = B * H * W;
+  dim3 grid((M + 3) / 4);
+  if (dtype == IDF_BF16)
+    hipLaunchKernelGGL(ln_kernel<IDF_BF16>, grid, dim3(256), 0, s, (const unsigned short*)x, C, (unsigned short*)out, ldo, gamma, beta, M, C, eps, H, W);
+  else if (dtype == IDF_F16)
+    hipLaunchKernelGGL(ln_kernel<IDF_F16>, grid, dim3(256), 0, s, (const unsigned short*)x, C, (unsigned short*)out, ldo, gamma, beta, M, C, eps, H, W);
   else
     return IDF_E_UNSUPPORTED;
   return idf_launch_status();

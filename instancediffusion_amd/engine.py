@@ -245,6 +245,76 @@ class UNetEngine:
             polygon=self._f32(pn.null_polygon_feature), seg=self._f32(pn.null_seg_feature))
         self.tok_pos = self._f32(pn.pos_embedding)            # [1, 64, 3072]
         self.tok_freqs = (100.0 ** (torch.arange(16) / 16)).to(device=self.device, dtype=torch.float32)
+        self._pack_convnext(pn)
+
+    def _pack_convnext(self, pn):
+        """ConvNeXt-T mask backbone (convnext.py:52-110) as GEMM images: stem 4x4/s4 and downsample 2x2/s2 convs are
+        patch GEMMs; the layer-scale gamma (convnext.py:45-46) is folded into pwconv2; K is zero-padded to 64-multiples."""
+        bb = pn.convnext_tiny_backbone
+        cn = dict(in_w=self._f32(pn.in_conv.weight), in_b=self._f32(pn.in_conv.bias), stages=[], down=[])
+        stem = bb.downsample_layers[0]
+        w = stem[0].weight.detach().float().reshape(stem[0].weight.shape[0], -1)           # [96, 48] (c, ky, kx)
+        wp = torch.zeros(w.shape[0], 64)
+        wp[:, :w.shape[1]] = w
+        cn["stem"] = _Lin(self._w16(wp), self._f32(stem[0].bias))
+        cn["stem_ln"] = (self._f32(stem[1].weight), self._f32(stem[1].bias))
+        for i in range(1, 4):
+            dl = bb.downsample_layers[i]
+            wd = dl[1].weight.detach().float()                                              # [Cout, Cin, 2, 2]
+            cn["down"].append(dict(ln=(self._f32(dl[0].weight), self._f32(dl[0].bias)),
+                                   conv=_Lin(self._w16(wd.permute(0, 2, 3, 1).reshape(wd.shape[0], -1)),
+                                             self._f32(dl[1].bias))))
+        for i in range(4):
+            blocks = []
+            for _, blk in bb.stages[i].items():
+                C = blk.dwconv.weight.shape[0]
+                kpad = _round_up(C, 64)
+                w1 = torch.zeros(4 * C, kpad)
+                w1[:, :C] = blk.pwconv1.weight.detach().float()
+                g = blk.gamma.detach().float()
+                blocks.append(dict(
+                    C=C, kpad=kpad,
+                    dw_w=self._f32(blk.dwconv.weight.detach().float().reshape(C, 49).t().contiguous()),   # [49][C]
+                    dw_b=self._f32(blk.dwconv.bias), ln=(self._f32(blk.norm.weight), self._f32(blk.norm.bias)),
+                    l1=_Lin(self._w16(w1), self._f32(blk.pwconv1.bias)),
+                    l2=_Lin(self._w16(g[:, None] * blk.pwconv2.weight.detach().float()),
+                            self._f32(g * blk.pwconv2.bias.detach().float()))))
+            cn["stages"].append(blocks)
+        self.cn = cn
+        t = torch.arange(64)
+        i = torch.arange(3072)
+        # text_grounding_net.py:230-231: feat[B,768,16,16].reshape(B,3072,64).permute(0,2,1)
+        #   token t, feature i  <-  feat[c = i//4, h = (i%4)*4 + t//16, w = t%16]
+        self.seg_gather = (((i[None, :] % 4) * 4 + t[:, None] // 16) * 16 + (t[:, None] % 16)) * 768 + i[None, :] // 4
+        self.seg_gather = self.seg_gather.to(self.device)
+
+    def convnext_features(self, segs: torch.Tensor) -> torch.Tensor:
+        """in_conv + ConvNeXt-T forward_features on the mask stack -> NHWC feature map [B, S/32, S/32, 768]."""
+        ops, cn = self.ops, self.cn
+        B, Cin, S, _ = segs.shape
+        P = S // 4
+        pm = ops.zeros((B * P * P, 64))
+        ops.seg_in_conv(segs.contiguous(), cn["in_w"], cn["in_b"], pm)
+        x = ops.gemm(pm, cn["stem"].w, ops.empty((B * P * P, cn["stem"].w.shape[0])), bias=cn["stem"].b)
+        C = x.shape[1]
+        x = ops.layernorm(x, ops.empty(x.shape), cn["stem_ln"][0], cn["stem_ln"][1], 1e-6).view(B, P, P, C)
+        H = P
+        for i in range(4):
+            if i > 0:
+                d = cn["down"][i - 1]
+                pmat = ops.layernorm_patch2(x, ops.empty((B * (H // 2) * (H // 2), 4 * C)), d["ln"][0], d["ln"][1], 1e-6)
+                H //= 2
+                Cn = d["conv"].w.shape[0]
+                x = ops.gemm(pmat, d["conv"].w, ops.empty((B * H * H, Cn)), bias=d["conv"].b).view(B, H, H, Cn)
+                C = Cn
+            M = B * H * H
+            for blk in cn["stages"][i]:
+                y = ops.dwconv7x7(x, blk["dw_w"], blk["dw_b"], ops.empty(x.shape))
+                ln = ops.zeros((M, blk["kpad"])) if blk["kpad"] != C else ops.empty((M, C))
+                ops.layernorm(y.view(M, C), ln[:, :C], blk["ln"][0], blk["ln"][1], 1e-6)
+                hmid = ops.gemm(ln, blk["l1"].w, ops.empty((M, 4 * C)), bias=blk["l1"].b, act="gelu")
+                ops.gemm(hmid, blk["l2"].w, x.view(M, C), bias=blk["l2"].b, res=x.view(M, C))
+        return x
 
     # =================================================================================================
     # alpha gate (utils/model.py:78-81 set_alpha_scale semantics)
@@ -313,17 +383,25 @@ class UNetEngine:
         # --- segmentation tokens (text_grounding_net.py:226-231, 279-285)
         segs = g["segs"]
         use_segs = (not drop_segs) and bool((segs.reshape(B, -1).sum(1) > 0).any())
-        if use_segs:
-            raise NotImplementedError(
-                "instance-mask (ConvNeXt) tokens are not built yet in the HIP path (SURVEY.md §8 config C4); "
-                "refusing to silently substitute the null feature")
-        seg_in = (self.tok_null["seg"].view(1, 1, -1) + self.tok_pos).reshape(64, -1)        # null path, batch-indep.
-        seg16 = ops.cast16(seg_in.contiguous(), ops.empty(seg_in.shape))
         l0, l1, l2 = self.tok_mlps[4]
-        h0 = ops.gemm(seg16, l0.w, ops.empty((64, l0.w.shape[0])), bias=l0.b, act="silu")
-        h1 = ops.gemm(h0, l1.w, ops.empty((64, l1.w.shape[0])), bias=l1.b, act="silu")
-        seg_tok = ops.gemm(h1, l2.w, ops.empty((64, l2.w.shape[0])), bias=l2.b)
-        objs[:, 4 * N:, :] = seg_tok.unsqueeze(0)
+        null_in = self.tok_null["seg"].view(1, 1, -1) + self.tok_pos                         # [1, 64, 3072]
+        if use_segs:
+            segs_r = segs.to(dev, torch.float32)
+            if segs_r.shape[-1] != pn.resize_input:                                          # :227 nearest resize
+                segs_r = torch.nn.functional.interpolate(segs_r, pn.resize_input, mode="nearest")
+            feat = self.convnext_features(segs_r)                                            # [B, 16, 16, 768]
+            sf = feat.reshape(B, -1).float()[:, self.seg_gather.reshape(-1)].reshape(B, 64, -1)   # :230-231 layout
+            sm = (segs_r.reshape(B, -1).sum(1) > 0).float().view(B, 1, 1)                    # :279
+            seg_in = sf * sm + (1 - sm) * self.tok_null["seg"].view(1, 1, -1) + self.tok_pos  # :282-285
+            rows = B * 64
+        else:
+            seg_in, rows = null_in, 64                                                       # batch-independent
+        seg_in = seg_in.reshape(rows, -1).contiguous()
+        seg16 = ops.cast16(seg_in, ops.empty(seg_in.shape))
+        h0 = ops.gemm(seg16, l0.w, ops.empty((rows, l0.w.shape[0])), bias=l0.b, act="silu")
+        h1 = ops.gemm(h0, l1.w, ops.empty((rows, l1.w.shape[0])), bias=l1.b, act="silu")
+        seg_tok = ops.gemm(h1, l2.w, ops.empty((rows, l2.w.shape[0])), bias=l2.b)
+        objs[:, 4 * N:, :] = seg_tok.view(-1, 64, seg_tok.shape[-1])
         return objs
 
     def _st_layers(self):

@@ -182,6 +182,29 @@ class HipOps:
                                           float(eps), self.dt, self._stream()), "idf_layernorm")
         return out
 
+    def layernorm_patch2(self, x, out, gamma, beta, eps):
+        """x [B,H,W,C] contiguous; out [B*(H/2)*(W/2), >=4C] rows in 2x2 patch order."""
+        B, H, W_, Cc = x.shape
+        assert x.is_contiguous() and out.stride(-1) == 1
+        _lib.check(self.lib.idf_layernorm_patch2(_p(x), _p(out), out.stride(0), _p(gamma), _p(beta), B, H, W_, Cc,
+                                                 float(eps), self.dt, self._stream()), "idf_layernorm_patch2")
+        return out
+
+    def seg_in_conv(self, segs, w, bias, out):
+        """segs fp32 [B,Cin,S,S]; out [B*(S/4)^2, ld>=48] 16-bit stem patch matrix."""
+        B, Cin, S, _ = segs.shape
+        assert segs.is_contiguous() and segs.dtype == torch.float32
+        _lib.check(self.lib.idf_seg_in_conv(_p(segs), _p(w), _p(bias), _p(out), B, Cin, S, out.stride(0), self.dt,
+                                            self._stream()), "idf_seg_in_conv")
+        return out
+
+    def dwconv7x7(self, x, w_tap_major, bias, out):
+        B, H, W_, Cc = x.shape
+        assert x.is_contiguous() and out.is_contiguous()
+        _lib.check(self.lib.idf_dwconv7x7(_p(x), _p(w_tap_major), _p(bias), _p(out), B, H, W_, Cc, self.dt,
+                                          self._stream()), "idf_dwconv7x7")
+        return out
+
     def scaleu_concat(self, h, skip, out, hscale, sm1):
         B, H, W_, Ch = h.shape
         Cs = skip.shape[-1]

@@ -128,6 +128,31 @@ class EmulOps:
         out.copy_(F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps))
         return out
 
+    def layernorm_patch2(self, x, out, gamma, beta, eps):
+        self._count("layernorm_patch2")
+        B, H, W_, C = x.shape
+        y = F.layer_norm(x.float(), (C,), gamma, beta, eps)
+        y = y.reshape(B, H // 2, 2, W_ // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B * (H // 2) * (W_ // 2), 4 * C)
+        out[:, :4 * C] = y.to(out.dtype)
+        return out
+
+    def seg_in_conv(self, segs, w, bias, out):
+        self._count("seg_in_conv")
+        B, Cin, S, _ = segs.shape
+        y = F.conv2d(segs, w, bias, padding=1)                       # [B,3,S,S]
+        P = S // 4
+        y = y.reshape(B, 3, P, 4, P, 4).permute(0, 2, 4, 1, 3, 5).reshape(B * P * P, 48)
+        out[:, :48] = y.to(out.dtype)
+        return out
+
+    def dwconv7x7(self, x, w_tap_major, bias, out):
+        self._count("dwconv7x7")
+        C = x.shape[-1]
+        w = w_tap_major.t().reshape(C, 1, 7, 7)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, padding=3, groups=C)
+        out.copy_(y.permute(0, 2, 3, 1))
+        return out
+
     def scaleu_concat(self, h, skip, out, hscale, sm1):
         self._count("scaleu_concat")
         B, H, W_, Ch = h.shape

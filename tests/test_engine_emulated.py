@@ -25,6 +25,7 @@ def build_model(cfg):
 
 @pytest.mark.parametrize("tag,dtype,tol", [
     ("tiny_box", torch.float32, 3e-4), ("tiny_point", torch.float32, 3e-4), ("mid_box", torch.float32, 3e-4),
+    ("tiny_mask", torch.float32, 3e-4), ("tiny_scribble", torch.float32, 3e-4), ("tiny_mask", torch.bfloat16, 4e-2),
     ("tiny_box", torch.bfloat16, 4e-2), ("mid_box", torch.bfloat16, 4e-2),
 ])
 def test_engine_forward_vs_reference(tag, dtype, tol):

@@ -36,7 +36,7 @@ def _check(eps, want, what):
     assert mx < 0.15, f"{what}: max-abs/rms {mx}"
 
 
-@pytest.mark.parametrize("tag", ["tiny_box", "tiny_point", "mid_box"])
+@pytest.mark.parametrize("tag", ["tiny_box", "tiny_point", "mid_box", "tiny_mask", "tiny_scribble"])
 def test_forward_matches_reference_golden(tag):
     from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
     gold, meta, cfg, inp = _case(tag)

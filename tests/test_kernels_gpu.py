@@ -314,3 +314,38 @@ def test_small_kernels(ops, ref):
         got = ops.mis_merge(dev(lat), dev(boxes), ops.empty((2, 4, 16, 16), torch.float32), mode)
         torch.cuda.synchronize()
         assert relmax(got, want) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# UniFusion mask-tokenizer pieces (ConvNeXt)
+# ---------------------------------------------------------------------------------------------------
+def test_convnext_pieces(ops, ref):
+    # seg_in_conv: 30 -> 3 conv written as the stem patch matrix
+    segs = (torch.rand(2, 30, 64, 64, generator=torch.Generator().manual_seed(80)) > 0.6).float()
+    w, b = gen((3, 30, 3, 3), 81, 0.1), gen((3,), 82)
+    want = ref.seg_in_conv(segs, w, b, torch.zeros(2 * 16 * 16, 64))
+    out = ops.seg_in_conv(dev(segs), dev(w), dev(b), ops.zeros((2 * 16 * 16, 64)))
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+    # depthwise 7x7
+    for (B, H, C) in [(2, 16, 96), (1, 8, 768), (1, 32, 192)]:
+        x = to16(gen((B, H, H, C), 83))
+        wt, bb = gen((49, C), 84, 1 / 7), gen((C,), 85)
+        want = ref.dwconv7x7(x.float(), wt, bb, torch.empty(B, H, H, C))
+        out = ops.dwconv7x7(dev(x), dev(wt), dev(bb), ops.empty((B, H, H, C)))
+        torch.cuda.synchronize()
+        assert relmax(out, want) < BF16_TOL
+    # LayerNorm + 2x2 patch gather
+    x = to16(gen((2, 8, 8, 96), 86) * 2 + 0.5)
+    gm, bt = 1 + 0.1 * gen((96,), 87), 0.1 * gen((96,), 88)
+    want = ref.layernorm_patch2(x.float(), torch.zeros(2 * 16, 384), gm, bt, 1e-6)
+    out = ops.layernorm_patch2(dev(x), ops.zeros((2 * 16, 384)), dev(gm), dev(bt), 1e-6)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+    # LayerNorm into a K-padded buffer (C = 96 -> ld 128), pad stays zero
+    x2 = to16(gen((100, 96), 89))
+    buf = ops.zeros((100, 128))
+    ops.layernorm(dev(x2), buf[:, :96], dev(gm), dev(bt), 1e-6)
+    torch.cuda.synchronize()
+    assert relmax(buf[:, :96], ref.layernorm(x2.float(), torch.empty(100, 96), gm, bt, 1e-6)) < BF16_TOL
+    assert float(buf[:, 96:].float().abs().max()) == 0.0

@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--images-per-gpu", type=int, default=8)   # reference default --num_images 8 (README.md:122-132)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -158,22 +158,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
   int tap = 0, ci0 = 0;                                // conv: K-tile -> (3x3 tap, channel offset)
   if (CONV) { tap = (kt_begin * BK) / p.Cin; ci0 = kt_begin * BK - tap * p.Cin; }
 
-  u32x4 ra[AR], rw[WR];
-  auto load_tile = [&](int kt) {
+  // two register sets: tile kt+1 waits in one while tile kt+2 is being fetched into the other (2-deep prefetch,
+  // so a global load has two K-tile iterations of MFMA time to land before its ds_write needs it)
+  u32x4 raA[AR], rwA[WR], raB[AR], rwB[WR];
+  unsigned okA = 0, okB = 0;                           // conv: per-row 'tap inside the image' bits of the staged tile
+  auto load_tile = [&](int kt, u32x4* ra, u32x4* rw, unsigned& okbits) {
 #pragma unroll
     for (int i = 0; i < WR; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)(kt_begin + kt) * BK);
     if (CONV) {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+      unsigned bits = 0;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        int yi = ay[i] + ky, xi = ax[i] + kx;
-        bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
-        int ys = yi >> p.up, xs = xi >> p.up;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *reinterpret_cast<const u32x4*>(arow[i] + ((size_t)ys * p.Win + xs) * p.lda + ci0);
-        ra[i] = v;
+        const int yi = ay[i] + ky, xi = ax[i] + kx;
+        const bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
+        // UNCONDITIONAL load from a clamped (always valid) pixel; the padding taps are zeroed at ds_write time
+        // (store_tile) so the number of outstanding loads is static and the counted vmcnt waits stay exact.
+        const int ys = min(max(yi, 0), Hup - 1) >> p.up, xs = min(max(xi, 0), Wup - 1) >> p.up;
+        ra[i] = *reinterpret_cast<const u32x4*>(arow[i] + ((size_t)ys * p.Win + xs) * p.lda + ci0);
+        bits |= (ok ? 1u : 0u) << i;
       }
+      okbits = bits;
       ci0 += BK;
       if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
     } else {
@@ -181,11 +187,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
       for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const u32x4*>(arow[i] + (size_t)(kt_begin + kt) * BK);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const u32x4* ra, const u32x4* rw, unsigned okbits) {
     unsigned short* Al = smem + buf * BUF;
     unsigned short* Wl = Al + BM * LSTR;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4*>(Al + (r0 + 32 * i) * LSTR + c * 8) = ra[i];
+    for (int i = 0; i < AR; ++i) {
+      u32x4 v = ra[i];
+      if (CONV) {
+        const unsigned keep = ((okbits >> i) & 1u) ? 0xffffffffu : 0u;
+        v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+      }
+      *reinterpret_cast<u32x4*>(Al + (r0 + 32 * i) * LSTR + c * 8) = v;
+    }
 #pragma unroll
     for (int i = 0; i < WR; ++i) *reinterpret_cast<u32x4*>(Wl + (r0 + 32 * i) * LSTR + c * 8) = rw[i];
   };
@@ -198,13 +211,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) load_tile(kt + 1);
-    const unsigned short* Al = smem + (kt & 1) * BUF;
+  auto compute = [&](int buf) {
+    const unsigned short* Al = smem + buf * BUF;
     const unsigned short* Wl = Al + BM * LSTR;
     const unsigned short* af_base = Al + (wm * WM + l31) * LSTR + hi * 8;
     const unsigned short* wf_base = Wl + (wn * WN + l31) * LSTR + hi * 8;
@@ -220,8 +228,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[a], af[b], acc[a][b]);
     }
-    if (more) store_tile((kt + 1) & 1);
+  };
+
+  load_tile(0, raA, rwA, okA);
+  store_tile(0, raA, rwA, okA);
+  if (nk > 1) load_tile(1, raA, rwA, okA);
+  __syncthreads();
+  // Invariant at the top of each pair of steps: LDS buffer 0 holds tile kt, register set A holds tile kt+1 (in flight).
+  // The steady-state loop issues its loads UNCONDITIONALLY so the compiler's counted vmcnt waits leave the newest
+  // tile's loads in flight across the ds_write + barrier; the <= 3 remaining tiles are peeled below.
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 2) {
+    load_tile(kt + 2, raB, rwB, okB);
+    __builtin_amdgcn_sched_barrier(0);         // keep the loads issued BEFORE the MFMAs (hipcc otherwise sinks them)
+    compute(0);
+    store_tile(1, raA, rwA, okA);
     __syncthreads();
+    load_tile(kt + 3, raA, rwA, okA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    store_tile(0, raB, rwB, okB);
+    __syncthreads();
+  }
+  const int rem = nk - kt;                     // 1, 2 or 3 tiles left
+  if (rem == 3) {
+    load_tile(kt + 2, raB, rwB, okB);
+    compute(0);
+    store_tile(1, raA, rwA, okA);
+    __syncthreads();
+    compute(1);
+    store_tile(0, raB, rwB, okB);
+    __syncthreads();
+    compute(0);
+  } else if (rem == 2) {
+    compute(0);
+    store_tile(1, raA, rwA, okA);
+    __syncthreads();
+    compute(1);
+  } else {
+    compute(0);
   }
 
   // ---- epilogue.  acc[a][b][r]: n = nb + (r&3) + 8*(r>>2) + 4*hi ; m = mb + l31

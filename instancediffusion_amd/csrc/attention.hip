@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int KVT = 64;            // kv rows per tile
-constexpr int VSTR = 68;           // V^T LDS row stride in elements (136 B: odd number of 8-B slots)
+constexpr int VSTR = 72;           // V^T LDS row stride in elements (144 B = 9 x 16-B slots: conflict-free b128 reads)
 
 struct AttnParams {
   const unsigned short* q; int ldq; long long sQ; int nq;
@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   constexpr int KSTR = (2 * NKS + 1) * 8;          // K LDS row stride (elements): odd number of 16-B slots
   constexpr int KCH_MAX = (KVT * 2 * NKS + 255) / 256;
   constexpr int VCH_MAX = (NMT * 32 * 8 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned short Kl[KVT * KSTR];
-  __shared__ __attribute__((aligned(16))) unsigned short Vl[NMT * 32 * VSTR];
+  constexpr int KSZ = KVT * KSTR, VSZ = NMT * 32 * VSTR;
+  __shared__ __attribute__((aligned(16))) unsigned short Kl[2 * KSZ];     // double-buffered: ONE barrier per KV tile
+  __shared__ __attribute__((aligned(16))) unsigned short Vl[2 * VSZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   const int qrow = blockIdx.x * 128 + wave * 32 + l31;
 
   // zero LDS once: pad columns of K (d..16*NKS) and pad rows of V^T (d..32*NMT) must stay finite zeros
-  for (int i = tid; i < KVT * KSTR / 2; i += 256) reinterpret_cast<unsigned*>(Kl)[i] = 0u;
-  for (int i = tid; i < NMT * 32 * VSTR / 2; i += 256) reinterpret_cast<unsigned*>(Vl)[i] = 0u;
+  for (int i = tid; i < KSZ; i += 256) reinterpret_cast<unsigned*>(Kl)[i] = 0u;
+  for (int i = tid; i < VSZ; i += 256) reinterpret_cast<unsigned*>(Vl)[i] = 0u;
 
   // ---- Q fragments (B operand): lane holds q = l31, e = 16*ks + 8*hi .. +7
   u32x4 qf[NKS];
@@ -76,13 +77,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     k_col[i] = ch * 8;
     k_lds[i] = row * KSTR + ch * 8;
   }
+  // V^T LDS image: inside each group of 16 kv the order is [0-3, 8-11, 4-7, 12-15], i.e. the k-permutation of the
+  // packed P fragment, so that the PV A-fragment of lane-half `hi` is ONE 16-B ds_read_b128 at group*32 B + hi*16 B.
+  // A staged 16-B chunk (8 consecutive kv, chunk index ch) therefore lands as two 8-B halves:
+  //   low half -> group*16 + (ch&1)*4 elements, high half -> +8 elements.
   int v_lds[VCH_MAX], v_row[VCH_MAX];
   const int v_ch8 = (tid & 7) * 8;
+  const int v_dst = ((tid & 7) >> 1) * 16 + ((tid & 7) & 1) * 4;
 #pragma unroll
   for (int i = 0; i < VCH_MAX; ++i) {
     const int row = (tid + i * 256) >> 3;
     v_row[i] = row < d ? row : -1;
-    v_lds[i] = row * VSTR + v_ch8;
+    v_lds[i] = row * VSTR + v_dst;
   }
 
   u32x4 kreg[KCH_MAX], vreg[VCH_MAX];
@@ -120,17 +126,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
       vreg[i] = v;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    unsigned short* Kb = Kl + buf * KSZ;
+    unsigned short* Vb = Vl + buf * VSZ;
 #pragma unroll
     for (int i = 0; i < KCH_MAX; ++i)
-      if (k_row[i] >= 0) *reinterpret_cast<u32x4*>(Kl + k_lds[i]) = kreg[i];
+      if (k_row[i] >= 0) *reinterpret_cast<u32x4*>(Kb + k_lds[i]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < VCH_MAX; ++i)
       if (v_row[i] >= 0) {
-        // VSTR*2 = 136 B rows are only 8-B aligned: two 8-B stores
         u32x2 lo = {vreg[i][0], vreg[i][1]}, hi2 = {vreg[i][2], vreg[i][3]};
-        *reinterpret_cast<u32x2*>(Vl + v_lds[i]) = lo;
-        *reinterpret_cast<u32x2*>(Vl + v_lds[i] + 4) = hi2;
+        *reinterpret_cast<u32x2*>(Vb + v_lds[i]) = lo;
+        *reinterpret_cast<u32x2*>(Vb + v_lds[i] + 8) = hi2;
       }
   };
 
@@ -143,11 +150,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   const float c = p.scale_log2;
 
   prefetch(0);
+  __syncthreads();              // zero-fill of both LDS buffers complete
+  commit(0);
+  if (T > 1) prefetch(1);
+  __syncthreads();
   for (int t = 0; t < T; ++t) {
-    __syncthreads();            // every wave finished reading the previous tile (and the zero-fill, t == 0)
-    commit();
-    __syncthreads();
-    if (t + 1 < T) prefetch(t + 1);
+    // Invariant: buffer t&1 holds tile t (visible to all waves); registers hold tile t+1 (loads in flight).
+    const unsigned short* Kc = Kl + (t & 1) * KSZ;
+    const unsigned short* Vc = Vl + (t & 1) * VSZ;
 
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     f32x16 s[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      const unsigned short* kf = Kl + (st * 32 + l31) * KSTR + hi * 8;
+      const unsigned short* kf = Kc + (st * 32 + l31) * KSTR + hi * 8;
       {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 a = *reinterpret_cast<const u32x4*>(kf);
@@ -211,17 +221,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         u32x4 pf;
 #pragma unroll
         for (int w = 0; w < 4; ++w) pf[w] = pack2<DT>(s[st][8 * k2 + 2 * w], s[st][8 * k2 + 2 * w + 1]);
-        const int kvoff = st * 32 + 16 * k2 + 4 * hi;
+        const int kvoff = st * 32 + 16 * k2 + 8 * hi;      // permuted image: lane-half hi owns 8 contiguous elements
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
-          const unsigned short* vf = Vl + (mt * 32 + l31) * VSTR + kvoff;
-          u32x2 v0 = *reinterpret_cast<const u32x2*>(vf);
-          u32x2 v1 = *reinterpret_cast<const u32x2*>(vf + 8);
-          u32x4 a = {v0[0], v0[1], v1[0], v1[1]};
+          const u32x4 a = *reinterpret_cast<const u32x4*>(Vc + (mt * 32 + l31) * VSTR + kvoff);
           o[mt] = Elem<DT>::mfma32(a, pf, o[mt]);
         }
       }
     }
+    // stage the next tile into the OTHER buffer (last read in iteration t-1; every wave passed that barrier), then
+    // fetch tile t+2 into the registers; one barrier per tile.
+    if (t + 1 < T) {
+      commit((t + 1) & 1);
+      if (t + 2 < T) prefetch(t + 2);
+    }
+    __syncthreads();
   }
 
   // ---- normalise and store.  o[mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31

@@ -26,53 +26,54 @@ struct CoreParams {
 constexpr int BK = 64;
 constexpr int LSTR = 72;   // LDS row stride in elements (144 B)
 
-// epilogue for 4 consecutive output columns n..n+3 of row m (shared by the main kernel and the split-K reducer)
+// Epilogue for 8 consecutive output columns n..n+7 of row m (n % 8 == 0).  Shared by the main kernel (after the
+// accumulators were transposed through LDS so that a lane owns a contiguous 8-column run -> 16-B coalesced residual /
+// rowbias loads and FULL-LINE 16-B stores) and by the split-K reducer.
 template <int DT>
-__device__ __forceinline__ void epilogue4(const CoreParams& p, int bz, int m, int n, float* v, float gate) {
+__device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, int n, float* v, float gate) {
   const int epi = p.epi;
-  const bool full = (n + 3 < p.N);
+  const bool full = (n + 7 < p.N);
   if (epi & IDF_EPI_BIAS) {
-    if (full) {                                       // n % 4 == 0 and bias is 16-B aligned: one 16-B load
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (full) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
     }
   }
   if (epi & IDF_EPI_ROWBIAS) {
     const unsigned short* rb = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n;
-    if (full && ((p.ld_rowbias & 3) == 0)) {
-      const u32x2 r2 = *reinterpret_cast<const u32x2*>(rb);
-      v[0] += Elem<DT>::to_f32((unsigned short)(r2[0] & 0xffffu)); v[1] += Elem<DT>::to_f32((unsigned short)(r2[0] >> 16));
-      v[2] += Elem<DT>::to_f32((unsigned short)(r2[1] & 0xffffu)); v[3] += Elem<DT>::to_f32((unsigned short)(r2[1] >> 16));
+    if (full && ((p.ld_rowbias & 7) == 0)) {
+      float r[8];
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(rb), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
     }
   }
   if (epi & IDF_EPI_SILU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
   }
   if (epi & IDF_EPI_GELU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
   }
   if (epi & IDF_EPI_RES) {
     const unsigned short* rr = p.res + (size_t)bz * p.strideR + (size_t)m * p.ldr + n;
     const float gm = (epi & IDF_EPI_GATE) ? gate : 1.0f;
-    if (full && ((p.ldr & 3) == 0)) {
-      const u32x2 r2 = *reinterpret_cast<const u32x2*>(rr);
-      v[0] = fmaf(gm, v[0], Elem<DT>::to_f32((unsigned short)(r2[0] & 0xffffu)));
-      v[1] = fmaf(gm, v[1], Elem<DT>::to_f32((unsigned short)(r2[0] >> 16)));
-      v[2] = fmaf(gm, v[2], Elem<DT>::to_f32((unsigned short)(r2[1] & 0xffffu)));
-      v[3] = fmaf(gm, v[3], Elem<DT>::to_f32((unsigned short)(r2[1] >> 16)));
+    if (full && ((p.ldr & 7) == 0)) {
+      float r[8];
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(rr), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(gm, v[e], r[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < p.N) v[e] = fmaf(gm, v[e], Elem<DT>::to_f32(rr[e]));
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] = fmaf(gm, v[e], Elem<DT>::to_f32(rr[e]));
     }
   }
   if (epi & IDF_EPI_OUT_NCHW) {
@@ -80,20 +81,24 @@ __device__ __forceinline__ void epilogue4(const CoreParams& p, int bz, int m, in
     const int bb = m / hw, rem = m - bb * hw;
     float* o = reinterpret_cast<float*>(p.out);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 8; ++e)
       if (n + e < p.n_valid) o[((size_t)bb * p.n_valid + (n + e)) * hw + rem] = v[e];
   } else if (epi & IDF_EPI_OUT_F32) {
     float* o = reinterpret_cast<float*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) if (full || n + e < p.N) o[e] = v[e];
-  } else {
-    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
     if (full && ((p.ldo & 3) == 0)) {
-      u32x2 pk = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(o) = pk;
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = v[e];
+    }
+  } else {
+    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+    if (full && ((p.ldo & 7) == 0)) {
+      *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
     }
   }
 }
@@ -269,75 +274,114 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
     compute(0);
   }
 
-  // ---- epilogue.  acc[a][b][r]: n = nb + (r&3) + 8*(r>>2) + 4*hi ; m = mb + l31
+  // ---- epilogue.  acc[a][b][r] holds D[n = a*32 + (r&3) + 8*(r>>2) + 4*hi][m = b*32 + l31] of the wave's WM x WN tile.
+  // Transpose it through LDS (the K-loop tiles are dead now) so that each lane owns 8 CONSECUTIVE columns of one row:
+  // residual / rowbias loads become coalesced 16-B vectors and the output leaves as full 128-B lines (8 lanes x 16 B)
+  // instead of 16-B fragments scattered over 32 rows per store instruction.
+  constexpr int CSTR = WN + 4;                                   // fp32 row stride: rows 16-B aligned, bank-spread
+  static_assert(4 * WM * CSTR * 4 <= 2 * (BM + BN) * LSTR * 2, "C staging must fit in the K-loop LDS");
+  __syncthreads();
+  float* Cl = reinterpret_cast<float*>(smem) + wave * (WM * CSTR);
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(Cl + (b * 32 + l31) * CSTR + a * 32 + 8 * q + 4 * hi) =
+            f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+  __syncthreads();
+
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+  const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+  if (epi & IDF_EPI_GEGLU) {
+    if constexpr (WN >= 64) {
+      // wave columns are [32 value | 32 gate] per 64; a lane pairs value chunk c with gate chunk c of one row
+      constexpr int CHV = WN / 16;                               // value chunks (8 columns each) per row
+      constexpr int RPP = 64 / CHV;                              // rows per pass
 #pragma unroll
-  for (int b = 0; b < TM; ++b) {
-    const int m = m0 + wm * WM + b * 32 + l31;
-    if (m >= p.M) continue;
-    const int brow = (epi & IDF_EPI_ROWBIAS) ? (m / p.rows_per_batch) : 0;
-    if (epi & IDF_EPI_GEGLU) {
-      if constexpr (TN >= 2) {
+      for (int pass = 0; pass < WM / RPP; ++pass) {
+        const int row = pass * RPP + lane / CHV, c = lane % CHV;
+        const int pair = c >> 2, cc = c & 3;
+        const int m = mw + row;
+        const int npk = nw + pair * 64 + cc * 8;                 // packed weight row of the value columns
+        if (m < p.M && npk + 32 < p.N) {
+          const float* src = Cl + row * CSTR + pair * 64 + cc * 8;
+          float v[8], g[8];
+          *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+          *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+          *reinterpret_cast<f32x4*>(g) = *reinterpret_cast<const f32x4*>(src + 32);
+          *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(src + 36);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + npk), bv1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 4);
+          const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + npk + 32), bg1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 36);
 #pragma unroll
-        for (int a = 0; a < TN; a += 2) {
-          const int nb = n0 + wn * WN + a * 32;         // packed row base (multiple of 64)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int off = 8 * q + 4 * hi;
-            if (nb + 32 + off >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float xv = acc[a][b][4 * q + e] + p.bias[nb + off + e];
-              float gv = acc[a + 1][b][4 * q + e] + p.bias[nb + 32 + off + e];
-              v[e] = xv * gelu_erf_f(gv);
-            }
-            const int j = nb / 2 + off;
-            unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + j;
-            u32x2 pk = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(o) = pk;
+          for (int e = 0; e < 4; ++e) {
+            v[e] = (v[e] + bv0[e]) * gelu_erf_f(g[e] + bg0[e]);
+            v[e + 4] = (v[e + 4] + bv1[e]) * gelu_erf_f(g[e + 4] + bg1[e]);
+          }
+          const int j = (nw + pair * 64) / 2 + cc * 8;
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + j;
+          if ((p.ldo & 7) == 0) {
+            *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
+          } else {
+            const u32x4 pk = pack8<DT>(v);
+            *reinterpret_cast<u32x2*>(o) = u32x2{pk[0], pk[1]};
+            *reinterpret_cast<u32x2*>(o + 4) = u32x2{pk[2], pk[3]};
           }
         }
       }
-      continue;
     }
+    return;
+  }
+  constexpr int CH = WN / 8;                                     // 8-column chunks per row
+  constexpr int RPP = 64 / CH;                                   // rows per pass (one wave instruction = RPP full rows)
 #pragma unroll
-    for (int a = 0; a < TN; ++a) {
+  for (int pass = 0; pass < WM / RPP; ++pass) {
+    const int row = pass * RPP + lane / CH, c = lane % CH;
+    const int m = mw + row, n = nw + c * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const float* src = Cl + row * CSTR + c * 8;
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+    if (p.splitk > 1) {
+      float* o = p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + n;
+      if (n + 7 < p.N && ((p.N & 3) == 0)) {
+        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * WN + a * 32 + 8 * q + 4 * hi;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e];
-        if (p.splitk > 1) {
-          float* o = p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) o[e] = v[e];
-        } else {
-          epilogue4<DT>(p, bz, m, n, v, gate);
-        }
+        for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = v[e];
       }
+    } else {
+      epilogue8<DT>(p, bz, m, n, v, gate);
     }
   }
 }
 
-// out = epi(sum over K-slices) for split-K launches: one thread per 4 consecutive columns of one row
+// out = epi(sum over K-slices) for split-K launches: one thread per 8 consecutive columns of one row
 template <int DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) {
-  const int n4 = (p.N + 3) / 4;
+  const int n8 = (p.N + 7) / 8;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)p.M * n4) return;
-  const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i >= (size_t)p.M * n8) return;
+  const int m = (int)(i / n8), n = (int)(i - (size_t)m * n8) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool vec = (n + 7 < p.N) && ((p.N & 3) == 0);
   for (int s = 0; s < p.splitk; ++s) {
     const float* w = p.ws + ((size_t)s * p.M + m) * p.N + n;
+    if (vec) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += w[e];
+      for (int e = 0; e < 4; ++e) { v[e] += w0[e]; v[e + 4] += w1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += w[e];
+    }
   }
   const float gate = (p.epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
-  epilogue4<DT>(p, 0, m, n, v, gate);
+  epilogue8<DT>(p, 0, m, n, v, gate);
 }
 
 template <int DT, int BM, int BN, int WM, int WN, bool CONV>
@@ -368,8 +412,8 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
   dim3 grid(tiles, 1, q.splitk > 1 ? q.splitk : batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, q);
   if (q.splitk > 1) {
-    const size_t n4 = (size_t)q.M * ((q.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q);
+    const size_t n8 = (size_t)q.M * ((q.N + 7) / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, q);
   }
   return idf_launch_status();
 }

@@ -102,6 +102,7 @@ class UNetModel(nn.Module):
         self.enable_se_scaleu = False
         self.first_conv_restorable = True
         self.first_conv_sd_override: Optional[Dict[str, torch.Tensor]] = None   # tests/bench: synthetic SD conv
+        self.compute_dtype = torch.bfloat16        # 16-bit storage / MFMA input type of the HIP engine (or float16)
 
         ted = model_channels * 4
         self.time_embed = Slots({0: Dense(model_channels, ted), 2: Dense(ted, ted)})
@@ -190,7 +191,7 @@ class UNetModel(nn.Module):
     def engine(self):
         if self._engine is None:
             from ..engine import UNetEngine      # imports the C-ABI loader; raises if the .so is missing
-            self._engine = UNetEngine(self)
+            self._engine = UNetEngine(self, dtype=self.compute_dtype)
         return self._engine
 
     def forward_single_input(self, input):

@@ -69,3 +69,19 @@ def test_reference_yaml_instantiates(name):
     assert type(model).__module__.startswith("instancediffusion_amd")
     assert diffusion.num_timesteps == 1000 and abs(float(diffusion.betas[0]) - 0.00085) < 1e-9
     assert model.position_net.eval_drops() is not None and hasattr(gi, "get_null_input")
+
+
+def test_inference_cli_input_builder():
+    """inference.py parses the reference's demo-JSON format into prepare_batch-shaped tensors."""
+    import json
+    import torch
+    import inference
+    from instancediffusion_amd import synth
+    data = json.load(open(os.path.join(REPO, "demos", "demo_four_boxes.json")))
+    batch, phrases = inference.build_batch(data, inference.SyntheticTextEncoder(), batch=2)
+    assert batch["boxes"].shape == (2, 30, 4) and batch["segs"].shape == (2, 30, 512, 512)
+    assert torch.allclose(batch["boxes"][0, :4], torch.tensor(synth.C1_BOXES), atol=2e-3)
+    assert batch["masks"][0].sum() == 4 and len(phrases) == 4
+    assert torch.allclose(batch["points"][0, 0], (batch["boxes"][0, 0, :2] + batch["boxes"][0, 0, 2:]) / 2)
+    inst = inference.instance_batch(batch, 2)
+    assert torch.equal(inst["boxes"][:, 0], batch["boxes"][:, 2]) and inst["masks"].sum() == 2

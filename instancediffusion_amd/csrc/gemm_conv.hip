@@ -9,6 +9,7 @@
 //
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops = 2*M*N*K.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -99,6 +100,98 @@ __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, in
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
+    }
+  }
+}
+
+// Tile epilogue shared by both K-loop variants (see the comment inside).
+template <int DT, int BM, int BN, int WM, int WN, int KLOOP_LDS_BYTES>
+__device__ __forceinline__ void tile_epilogue(const CoreParams& p, f32x16 (&acc)[WN / 32][WM / 32], unsigned short* smem,
+                                              int m0, int n0, int bz, int wm, int wn, int lane, int wave) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  const int l31 = lane & 31, hi = lane >> 5;
+  // ---- epilogue.  acc[a][b][r] holds D[n = a*32 + (r&3) + 8*(r>>2) + 4*hi][m = b*32 + l31] of the wave's WM x WN tile.
+  // Transpose it through LDS (the K-loop tiles are dead now) so that each lane owns 8 CONSECUTIVE columns of one row:
+  // residual / rowbias loads become coalesced 16-B vectors and the output leaves as full 128-B lines (8 lanes x 16 B)
+  // instead of 16-B fragments scattered over 32 rows per store instruction.
+  constexpr int CSTR = WN + 4;                                   // fp32 row stride: rows 16-B aligned, bank-spread
+  static_assert(4 * WM * CSTR * 4 <= KLOOP_LDS_BYTES, "C staging must fit in the allocated LDS");
+  __syncthreads();
+  float* Cl = reinterpret_cast<float*>(smem) + wave * (WM * CSTR);
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(Cl + (b * 32 + l31) * CSTR + a * 32 + 8 * q + 4 * hi) =
+            f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+  __syncthreads();
+
+  const int epi = p.epi;
+  const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+  const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+  if (epi & IDF_EPI_GEGLU) {
+    if constexpr (WN >= 64) {
+      // wave columns are [32 value | 32 gate] per 64; a lane pairs value chunk c with gate chunk c of one row
+      constexpr int CHV = WN / 16;                               // value chunks (8 columns each) per row
+      constexpr int RPP = 64 / CHV;                              // rows per pass
+#pragma unroll
+      for (int pass = 0; pass < WM / RPP; ++pass) {
+        const int row = pass * RPP + lane / CHV, c = lane % CHV;
+        const int pair = c >> 2, cc = c & 3;
+        const int m = mw + row;
+        const int npk = nw + pair * 64 + cc * 8;                 // packed weight row of the value columns
+        if (m < p.M && npk + 32 < p.N) {
+          const float* src = Cl + row * CSTR + pair * 64 + cc * 8;
+          float v[8], g[8];
+          *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+          *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+          *reinterpret_cast<f32x4*>(g) = *reinterpret_cast<const f32x4*>(src + 32);
+          *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(src + 36);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + npk), bv1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 4);
+          const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + npk + 32), bg1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 36);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = (v[e] + bv0[e]) * gelu_erf_f(g[e] + bg0[e]);
+            v[e + 4] = (v[e + 4] + bv1[e]) * gelu_erf_f(g[e + 4] + bg1[e]);
+          }
+          const int j = (nw + pair * 64) / 2 + cc * 8;
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + j;
+          if ((p.ldo & 7) == 0) {
+            *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
+          } else {
+            const u32x4 pk = pack8<DT>(v);
+            *reinterpret_cast<u32x2*>(o) = u32x2{pk[0], pk[1]};
+            *reinterpret_cast<u32x2*>(o + 4) = u32x2{pk[2], pk[3]};
+          }
+        }
+      }
+    }
+    return;
+  }
+  constexpr int CH = WN / 8;                                     // 8-column chunks per row
+  constexpr int RPP = 64 / CH;                                   // rows per pass (one wave instruction = RPP full rows)
+#pragma unroll
+  for (int pass = 0; pass < WM / RPP; ++pass) {
+    const int row = pass * RPP + lane / CH, c = lane % CH;
+    const int m = mw + row, n = nw + c * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const float* src = Cl + row * CSTR + c * 8;
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+    if (p.splitk > 1) {
+      float* o = p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + n;
+      if (n + 7 < p.N && ((p.N & 3) == 0)) {
+        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = v[e];
+      }
+    } else {
+      epilogue8<DT>(p, bz, m, n, v, gate);
     }
   }
 }
@@ -274,90 +367,178 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
     compute(0);
   }
 
-  // ---- epilogue.  acc[a][b][r] holds D[n = a*32 + (r&3) + 8*(r>>2) + 4*hi][m = b*32 + l31] of the wave's WM x WN tile.
-  // Transpose it through LDS (the K-loop tiles are dead now) so that each lane owns 8 CONSECUTIVE columns of one row:
-  // residual / rowbias loads become coalesced 16-B vectors and the output leaves as full 128-B lines (8 lanes x 16 B)
-  // instead of 16-B fragments scattered over 32 rows per store instruction.
-  constexpr int CSTR = WN + 4;                                   // fp32 row stride: rows 16-B aligned, bank-spread
-  static_assert(4 * WM * CSTR * 4 <= 2 * (BM + BN) * LSTR * 2, "C staging must fit in the K-loop LDS");
-  __syncthreads();
-  float* Cl = reinterpret_cast<float*>(smem) + wave * (WM * CSTR);
+  tile_epilogue<DT, BM, BN, WM, WN, 2 * (BM + BN) * LSTR * 2>(p, acc, smem, m0, n0, bz, wm, wn, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K-loop variant 2: LDS-DMA staging (global_load_lds_dwordx4) for every DENSE operand tile (the weight tile always, the
+// activation tile unless CONV).  The VGPR -> LDS store path (ds_write_b128 ~79 B/clk/CU) was the busiest pipe of
+// variant 1 -- 64 KB of tile stores per CU per K-tile pair against 1024 MFMA cycles; the DMA path bypasses it and frees
+// the staging registers.  An LDS-DMA instruction writes wave-uniform base + lane*16 B, so the tile image is LINEAR
+// 128-B rows (64 elements); bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on
+// the per-lane GLOBAL source address and, identically, on the reads:  LDS slot = k-chunk ^ ((row >> 1) & 7).
+// The conv activation gather keeps the register path (padding taps must be zeroed) and stores into the same image.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DT, int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_dma(const CoreParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int RS = 64;                                // LDS row stride (elements) = BK, no padding
+  constexpr int BUF = (BM + BN) * RS;
+  constexpr int W_INST = BN / 8 / 4, A_INST = BM / 8 / 4;     // DMA instructions (8 rows each) per wave per tile
+  constexpr int AR = BM / 32;
+  constexpr int KLOOP_LDS = 2 * BUF * 2;
+  constexpr int CSTAGE = 4 * WM * (WN + 4) * 4;
+  constexpr int LDS_BYTES = KLOOP_LDS > CSTAGE ? KLOOP_LDS : CSTAGE;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+  int tile;
+  {
+    const int T = gridDim.x, L = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = L & 7, i = L >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m_tile = tile / tiles_n;
+  const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
+  const int bz = (p.splitk > 1) ? 0 : blockIdx.z;
+  const unsigned short* Wb = p.W + (size_t)bz * p.strideW;
+  const unsigned short* Ab = p.A + (size_t)bz * p.strideA;
+
+  const int nk_all = p.K / BK;
+  const int kt_begin = (p.splitk > 1) ? blockIdx.z * p.kt_per_slice : 0;
+  const int nk = (p.splitk > 1) ? min(p.kt_per_slice, nk_all - kt_begin) : nk_all;
+
+  // ---- DMA roles: instruction j of this wave covers tile rows 8*(wave + 4 j) .. +7; lane -> (row r = lane>>3, slot c)
+  const int dr = lane >> 3, dc = lane & 7;
+  const unsigned short* wsrc[W_INST];
+#pragma unroll
+  for (int j = 0; j < W_INST; ++j) {
+    const int row = 8 * (wave + 4 * j) + dr;                     // tile-local row
+    const int n = min(n0 + row, p.N - 1);
+    wsrc[j] = Wb + (size_t)n * p.ldw + (size_t)kt_begin * BK + ((dc ^ ((row >> 1) & 7)) * 8);
+  }
+  const unsigned short* asrc[A_INST];
+  if (!CONV) {
+#pragma unroll
+    for (int j = 0; j < A_INST; ++j) {
+      const int row = 8 * (wave + 4 * j) + dr;
+      const int m = min(m0 + row, p.M - 1);
+      asrc[j] = Ab + (size_t)m * p.lda + (size_t)kt_begin * BK + ((dc ^ ((row >> 1) & 7)) * 8);
+    }
+  }
+  // ---- conv activation gather (register path): thread -> (16-B chunk c, rows r0 + 32 i)
+  const int c = tid & 7, r0 = tid >> 3;
+  const unsigned short* arow[AR];
+  int ay[AR], ax[AR];
+  int tap = 0, ci0 = 0;
+  if (CONV) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int m = min(m0 + r0 + 32 * i, p.M - 1);
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      ay[i] = yo * p.stride - 1;
+      ax[i] = xo * p.stride - 1;
+      arow[i] = Ab + (size_t)b * p.Hin * p.Win * p.lda + c * 8;
+    }
+    tap = (kt_begin * BK) / p.Cin;
+    ci0 = kt_begin * BK - tap * p.Cin;
+  }
+  const int a_sw = (c ^ ((r0 >> 1) & 7)) * 8;            // (row>>1)&7 == (r0>>1)&7 for rows r0 + 32 i
+  u32x4 ra[AR];
+  unsigned okbits = 0;
+
+  auto dma_tile = [&](int kt, int buf) {                // enqueue the LDS-DMA of K-tile kt into LDS buffer buf
+    unsigned short* Al = smem + buf * BUF;
+    unsigned short* Wl = Al + BM * RS;
+#pragma unroll
+    for (int j = 0; j < W_INST; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (size_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Wl + 8 * (wave + 4 * j) * RS), 16, 0, 0);
+    if (!CONV) {
+#pragma unroll
+      for (int j = 0; j < A_INST; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(Al + 8 * (wave + 4 * j) * RS), 16, 0, 0);
+    }
+  };
+  auto gather_tile = [&]() {                            // conv: issue the activation gather of the next K-tile
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int yi = ay[i] + ky, xi = ax[i] + kx;
+      const bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
+      const int ys = min(max(yi, 0), Hup - 1) >> p.up, xs = min(max(xi, 0), Wup - 1) >> p.up;
+      ra[i] = *reinterpret_cast<const u32x4*>(arow[i] + ((size_t)ys * p.Win + xs) * p.lda + ci0);
+      bits |= (ok ? 1u : 0u) << i;
+    }
+    okbits = bits;
+    ci0 += BK;
+    if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
+  };
+  auto scatter_tile = [&](int buf) {                    // conv: zero the padding taps and store into the swizzled image
+    unsigned short* Al = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      u32x4 v = ra[i];
+      const unsigned keep = ((okbits >> i) & 1u) ? 0xffffffffu : 0u;
+      v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+      *reinterpret_cast<u32x4*>(Al + (r0 + 32 * i) * RS + a_sw) = v;
+    }
+  };
+
+  f32x16 acc[TN][TM];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4*>(Cl + (b * 32 + l31) * CSTR + a * 32 + 8 * q + 4 * hi) =
-            f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-  __syncthreads();
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const int epi = p.epi;
-  const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
-  const int mw = m0 + wm * WM, nw = n0 + wn * WN;
-  if (epi & IDF_EPI_GEGLU) {
-    if constexpr (WN >= 64) {
-      // wave columns are [32 value | 32 gate] per 64; a lane pairs value chunk c with gate chunk c of one row
-      constexpr int CHV = WN / 16;                               // value chunks (8 columns each) per row
-      constexpr int RPP = 64 / CHV;                              // rows per pass
+  const int f_sw = (l31 >> 1) & 7;                      // read-side swizzle: fragment rows are (multiple of 32) + l31
+  auto compute = [&](int buf) {
+    const unsigned short* Al = smem + buf * BUF;
+    const unsigned short* Wl = Al + BM * RS;
+    const unsigned short* af_base = Al + (wm * WM + l31) * RS;
+    const unsigned short* wf_base = Wl + (wn * WN + l31) * RS;
 #pragma unroll
-      for (int pass = 0; pass < WM / RPP; ++pass) {
-        const int row = pass * RPP + lane / CHV, c = lane % CHV;
-        const int pair = c >> 2, cc = c & 3;
-        const int m = mw + row;
-        const int npk = nw + pair * 64 + cc * 8;                 // packed weight row of the value columns
-        if (m < p.M && npk + 32 < p.N) {
-          const float* src = Cl + row * CSTR + pair * 64 + cc * 8;
-          float v[8], g[8];
-          *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
-          *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
-          *reinterpret_cast<f32x4*>(g) = *reinterpret_cast<const f32x4*>(src + 32);
-          *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(src + 36);
-          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + npk), bv1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 4);
-          const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + npk + 32), bg1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 36);
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int slot = ((ks * 2 + hi) ^ f_sw) * 8;
+      u32x4 wf[TN], af[TM];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = (v[e] + bv0[e]) * gelu_erf_f(g[e] + bg0[e]);
-            v[e + 4] = (v[e + 4] + bv1[e]) * gelu_erf_f(g[e + 4] + bg1[e]);
-          }
-          const int j = (nw + pair * 64) / 2 + cc * 8;
-          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + j;
-          if ((p.ldo & 7) == 0) {
-            *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
-          } else {
-            const u32x4 pk = pack8<DT>(v);
-            *reinterpret_cast<u32x2*>(o) = u32x2{pk[0], pk[1]};
-            *reinterpret_cast<u32x2*>(o + 4) = u32x2{pk[2], pk[3]};
-          }
-        }
-      }
+      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[a], af[b], acc[a][b]);
     }
-    return;
-  }
-  constexpr int CH = WN / 8;                                     // 8-column chunks per row
-  constexpr int RPP = 64 / CH;                                   // rows per pass (one wave instruction = RPP full rows)
-#pragma unroll
-  for (int pass = 0; pass < WM / RPP; ++pass) {
-    const int row = pass * RPP + lane / CH, c = lane % CH;
-    const int m = mw + row, n = nw + c * 8;
-    if (m >= p.M || n >= p.N) continue;
-    const float* src = Cl + row * CSTR + c * 8;
-    float v[8];
-    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
-    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
-    if (p.splitk > 1) {
-      float* o = p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + n;
-      if (n + 7 < p.N && ((p.N & 3) == 0)) {
-        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = v[e];
-      }
-    } else {
-      epilogue8<DT>(p, bz, m, n, v, gate);
+  };
+
+  dma_tile(0, 0);
+  if (CONV) { gather_tile(); scatter_tile(0); }
+  __syncthreads();                                      // drains vmcnt: tile 0 landed
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      dma_tile(kt + 1, (kt + 1) & 1);                   // lands during the MFMAs of tile kt
+      if (CONV) gather_tile();
     }
+    compute(kt & 1);
+    if (CONV && more) scatter_tile((kt + 1) & 1);
+    __syncthreads();                                    // (kt+1) complete and visible; buffer kt&1 free for tile kt+2
   }
+  tile_epilogue<DT, BM, BN, WM, WN, LDS_BYTES>(p, acc, smem, m0, n0, bz, wm, wn, lane, wave);
 }
 
 // out = epi(sum over K-slices) for split-K launches: one thread per 8 consecutive columns of one row
@@ -384,15 +565,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
   epilogue8<DT>(p, 0, m, n, v, gate);
 }
 
+inline bool use_dma_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("IDF_GEMM_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 template <int DT, int BM, int BN, int WM, int WN, bool CONV>
 int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
-  auto kern = gemm_kernel<DT, BM, BN, WM, WN, CONV>;
-  constexpr int smem = 2 * (BM + BN) * LSTR * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const bool dma = use_dma_variant();
+  auto kern = dma ? gemm_kernel_dma<DT, BM, BN, WM, WN, CONV> : gemm_kernel<DT, BM, BN, WM, WN, CONV>;
+  constexpr int smem_v1 = 2 * (BM + BN) * LSTR * 2;
+  constexpr int kloop2 = 2 * (BM + BN) * 64 * 2, cstage = 4 * WM * (WN + 4) * 4;
+  constexpr int smem_v2 = kloop2 > cstage ? kloop2 : cstage;
+  const int smem = dma ? smem_v2 : smem_v1;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[dma ? 1 : 0]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set[dma ? 1 : 0] = true;
   }
   CoreParams q = p;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);

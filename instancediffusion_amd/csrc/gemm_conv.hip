@@ -565,15 +565,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
   epilogue8<DT>(p, 0, m, n, v, gate);
 }
 
-inline bool use_dma_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("IDF_GEMM_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
+// K-loop variant choice (measured on MI355X, profiles/r01_diag_B18_*): LDS-DMA staging wins for dense GEMMs
+// (+5..18 % on K >= 1280, ~0 on K = 320); the conv gather is faster with the 2-deep register prefetch of variant 1
+// (its activation tile cannot use DMA).  IDF_GEMM_DMA=0/1 forces one variant for A/B runs.
+inline bool use_dma_variant(bool conv) {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("IDF_GEMM_DMA"); v = e ? (e[0] == '0' ? 0 : 1) : -1; }
+  return v >= 0 ? (v == 1) : !conv;
 }
 
 template <int DT, int BM, int BN, int WM, int WN, bool CONV>
 int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
-  const bool dma = use_dma_variant();
+  const bool dma = use_dma_variant(CONV);
   auto kern = dma ? gemm_kernel_dma<DT, BM, BN, WM, WN, CONV> : gemm_kernel<DT, BM, BN, WM, WN, CONV>;
   constexpr int smem_v1 = 2 * (BM + BN) * LSTR * 2;
   constexpr int kloop2 = 2 * (BM + BN) * 64 * 2, cstage = 4 * WM * (WN + 4) * 4;

@@ -92,7 +92,7 @@ class OpTimer:
             s.record()
             r = fn(*a, **k)
             e.record()
-            self.records.append((name, self._work(name, a, k), s, e))
+            self.records.append((name, self._work(name, a, k), s, e, self._bytes(name, a, k)))
             return r
         return timed
 
@@ -111,15 +111,47 @@ class OpTimer:
             return 4.0 * q.shape[0] * q.shape[1] * (n0 + k.get("n1", 0)) * q.shape[2]
         return 0.0
 
+    @staticmethod
+    def _bytes(name, a, k):
+        """Algorithmic (compulsory) HBM bytes of one launch: every operand read once, the result written once."""
+        def nb(t):
+            return 0 if t is None else t.numel() * t.element_size()
+        if name == "gemm":
+            return nb(a[0]) + nb(a[1]) + nb(a[2]) + nb(k.get("res")) + nb(k.get("bias"))
+        if name == "conv3x3":
+            return nb(a[0]) + nb(a[1]) + nb(a[2]) + nb(k.get("res")) + nb(k.get("bias"))
+        if name == "attention":
+            q, k0, vt0, n0, out = a[0], a[1], a[2], a[3], a[4]
+            extra = nb(k.get("k1")) + nb(k.get("vt1"))
+            return 2 * (q.shape[0] * q.shape[1] * q.shape[2]) * 2 + 2 * q.shape[0] * n0 * q.shape[2] * 2 + extra
+        return 0
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, work, s, e in self.records:
-            d = agg.setdefault(name, dict(calls=0, ms=0.0, flops=0.0))
+        for name, work, s, e, nbytes in self.records:
+            d = agg.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += work
+            d["bytes"] += nbytes
         return agg
+
+
+def pmc_traffic(op_name, batch):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE, separate runs; profiles/README.md).  None when no pass exists for this batch."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        tab = json.load(open(path))
+        ent = tab.get(str(batch), {}).get(op_name)
+        return None if ent is None else dict(hbm_bytes_per_launch=ent["hbm_bytes_per_launch"],
+                                             algorithmic_bytes_per_launch=ent.get("algorithmic_bytes_per_launch"),
+                                             source=ent.get("source"))
+    except Exception:
+        return None
 
 
 def measure_roofline(engine, batch):
@@ -142,13 +174,15 @@ def measure_roofline(engine, batch):
     total_ms = sum(d["ms"] for d in agg.values())
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     name, d = dom
-    kern = {"conv3x3": "gemm_kernel<.., CONV=true> (implicit-GEMM 3x3 conv)", "gemm": "gemm_kernel<.., CONV=false>",
+    kern = {"conv3x3": "gemm_kernel<.., CONV=true> (implicit-GEMM 3x3 conv, 2-deep register prefetch)",
+            "gemm": "gemm_kernel_dma<.., CONV=false> (dense GEMM, LDS-DMA staging; 128x128 and 128x64 tiles)",
             "attention": "attn_kernel"}.get(name, name)
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     return dict(bound="mfma", kernel=kern, achieved=round(achieved, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
-                frac=round(achieved / PEAK_MFMA_TF, 4), traffic=None,
+                frac=round(achieved / PEAK_MFMA_TF, 4), traffic=pmc_traffic(name, batch),
                 launches_per_forward=d["calls"], avg_launch_us=round(d["ms"] * 1e3 / d["calls"], 2),
-                algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3), measured_at_batch=batch,
+                algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
+                algorithmic_mbytes_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2), measured_at_batch=batch,
                 forward_breakdown_ms={k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
                 forward_total_ms=round(total_ms, 3))
 

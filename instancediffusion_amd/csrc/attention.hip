@@ -29,7 +29,10 @@ struct AttnParams {
 };
 
 // NKS = ceil(d/16) K-steps of the QK^T contraction, NMT = ceil(d/32) 32-row tiles of O^T.
-template <int DT, int NKS, int NMT>
+// MFMASUM: d < 32*NMT, i.e. the O^T tile has spare rows -> row d of the V^T image is set to ONES so the softmax
+// denominator l = sum_j P[q][j] falls out of the PV MFMAs for free (no 32 VALU adds per tile per lane) and is rescaled
+// together with O.  (It then sums the 16-bit-rounded P, exactly the P that multiplies V.)
+template <int DT, int NKS, int NMT, bool MFMASUM>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   constexpr int KSTR = (2 * NKS + 1) * 8;          // K LDS row stride (elements): odd number of 16-B slots
   constexpr int KCH_MAX = (KVT * 2 * NKS + 255) / 256;
@@ -48,6 +51,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   // zero LDS once: pad columns of K (d..16*NKS) and pad rows of V^T (d..32*NMT) must stay finite zeros
   for (int i = tid; i < KSZ; i += 256) reinterpret_cast<unsigned*>(Kl)[i] = 0u;
   for (int i = tid; i < VSZ; i += 256) reinterpret_cast<unsigned*>(Vl)[i] = 0u;
+  if (MFMASUM) {                                      // "ones" row (element d) in both ring buffers; never overwritten
+    __syncthreads();
+    const unsigned short one = Elem<DT>::from_f32(1.0f);
+    for (int i = tid; i < 2 * KVT; i += 256) Vl[(i / KVT) * VSZ + d * VSTR + (i % KVT)] = one;
+  }
 
   // ---- Q fragments (B operand): lane holds q = l31, e = 16*ks + 8*hi .. +7
   u32x4 qf[NKS];
@@ -205,9 +213,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const float pv = __builtin_amdgcn_exp2f(fmaf(s[st][r], c, -m_new));
         s[st][r] = pv;
-        rs += pv;
+        if (!MFMASUM) rs += pv;
       }
-    l_run = l_run * alpha + rs;
+    if (!MFMASUM) l_run = l_run * alpha + rs;
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -239,7 +247,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 
   // ---- normalise and store.  o[mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if (MFMASUM) {
+    // row e = d of O^T: tile d/32, register 4*((d%32)/8) of the hi = 0 lanes (d % 8 == 0)
+    const int sel = (d & 31) >> 3;
+    const f32x16& ol = o[NMT - 1];
+    float lv = sel == 0 ? ol[0] : (sel == 1 ? ol[4] : (sel == 2 ? ol[8] : ol[12]));
+    l_tot = __shfl(lv, l31, 64);                       // broadcast from lane l31 (hi = 0) to its hi = 1 partner
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   if (qrow < p.nq) {
     unsigned short* op = p.out + (size_t)b * p.sO + (size_t)qrow * p.ldo + h * d;
@@ -262,7 +279,10 @@ int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   dim3 grid((p.nq + 127) / 128, p.H, B), block(256);
   const int nks = (p.d + 15) / 16, nmt = (p.d + 31) / 32;
 #define IDF_ATTN_CASE(KS, MT) \
-  if (nks == KS && nmt == MT) { hipLaunchKernelGGL((attn_kernel<DT, KS, MT>), grid, block, 0, s, p); return idf_launch_status(); }
+  if (nks == KS && nmt == MT) { \
+    if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false>), grid, block, 0, s, p); \
+    return idf_launch_status(); }
   IDF_ATTN_CASE(1, 1)    // d = 8, 16
   IDF_ATTN_CASE(2, 1)    // d = 24, 32
   IDF_ATTN_CASE(3, 2)    // d = 40, 48

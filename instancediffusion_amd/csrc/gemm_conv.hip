@@ -541,121 +541,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_dma(const CoreParams p) {
   tile_epilogue<DT, BM, BN, WM, WN, LDS_BYTES>(p, acc, smem, m0, n0, bz, wm, wn, lane, wave);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// K-loop variant 3 (dense GEMM only): a 4-stage LDS ring of 32-deep K-steps filled by LDS-DMA, THREE steps in flight.
-// PMC on variant 2 showed the dense GEMMs parked on memory (SQ_WAIT_ANY 44-67 % of wave cycles): one K-tile of
-// prefetch is ~0.25 us of MFMA work against ~1-2 us of HBM/L2 latency.  Here each wave keeps 3 x 4 DMA instructions
-// outstanding across the per-step barrier (counted `s_waitcnt vmcnt(8)`, raw s_barrier -- a __syncthreads() would drain
-// the DMA queue).  Stage image: 64-B rows (32 elements), slot = k-chunk ^ ((row >> 2) & 3) (conflict-free b128 reads).
-// ------------------------------------------------------------------------------------------------------------------
-template <int DT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_ring(const CoreParams p) {
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int WAVES_N = BN / WN;
-  constexpr int KS = 32, RS = 32, NST = 4;              // K-step, LDS row stride (elements), ring stages
-  constexpr int STG = (BM + BN) * RS;                   // elements per stage
-  constexpr int W_INST = BN / 16 / 4, A_INST = BM / 16 / 4;   // DMA instructions (16 rows each) per wave per step
-  constexpr int PER_STEP = W_INST + A_INST;
-  constexpr int RING_BYTES = NST * STG * 2;
-  constexpr int CSTAGE = 4 * WM * (WN + 4) * 4;
-  constexpr int LDS_BYTES = RING_BYTES > CSTAGE ? RING_BYTES : CSTAGE;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int wn = wave % WAVES_N, wm = wave / WAVES_N;
-  int tile;
-  {
-    const int T = gridDim.x, L = blockIdx.x;
-    const int q = T >> 3, r = T & 7, xcd = L & 7, i = L >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int m_tile = tile / tiles_n;
-  const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
-  const int bz = (p.splitk > 1) ? 0 : blockIdx.z;
-  const unsigned short* Wb = p.W + (size_t)bz * p.strideW;
-  const unsigned short* Ab = p.A + (size_t)bz * p.strideA;
-
-  const int nk_all = p.K / BK;                          // split-K bookkeeping stays in 64-deep tiles
-  const int kt_begin = (p.splitk > 1) ? blockIdx.z * p.kt_per_slice : 0;
-  const int nsteps = 2 * ((p.splitk > 1) ? min(p.kt_per_slice, nk_all - kt_begin) : nk_all);
-
-  const int dr = lane >> 2, dc = lane & 3;              // DMA lane role: row dr (0..15) of the instruction, 16-B slot dc
-  const unsigned short* wsrc[W_INST];
-  const unsigned short* asrc[A_INST];
-#pragma unroll
-  for (int j = 0; j < W_INST; ++j) {
-    const int row = 16 * (wave + 4 * j) + dr;
-    wsrc[j] = Wb + (size_t)min(n0 + row, p.N - 1) * p.ldw + (size_t)kt_begin * BK + ((dc ^ ((row >> 2) & 3)) * 8);
-  }
-#pragma unroll
-  for (int j = 0; j < A_INST; ++j) {
-    const int row = 16 * (wave + 4 * j) + dr;
-    asrc[j] = Ab + (size_t)min(m0 + row, p.M - 1) * p.lda + (size_t)kt_begin * BK + ((dc ^ ((row >> 2) & 3)) * 8);
-  }
-  auto dma_step = [&](int st) {                         // enqueue K-step st into ring stage st % NST
-    unsigned short* Al = smem + (st & (NST - 1)) * STG;
-    unsigned short* Wl = Al + BM * RS;
-#pragma unroll
-    for (int j = 0; j < W_INST; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (size_t)st * KS),
-                                       (__attribute__((address_space(3))) void*)(Wl + 16 * (wave + 4 * j) * RS), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < A_INST; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)st * KS),
-                                       (__attribute__((address_space(3))) void*)(Al + 16 * (wave + 4 * j) * RS), 16, 0, 0);
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-  const int f_sw = (l31 >> 2) & 3;
-  auto compute = [&](int st) {
-    const unsigned short* Al = smem + (st & (NST - 1)) * STG;
-    const unsigned short* Wl = Al + BM * RS;
-    const unsigned short* af_base = Al + (wm * WM + l31) * RS;
-    const unsigned short* wf_base = Wl + (wn * WN + l31) * RS;
-#pragma unroll
-    for (int ks = 0; ks < KS / 16; ++ks) {
-      const int slot = ((ks * 2 + hi) ^ f_sw) * 8;
-      u32x4 wf[TN], af[TM];
-#pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
-#pragma unroll
-      for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[a], af[b], acc[a][b]);
-    }
-  };
-
-  dma_step(0);
-  if (nsteps > 1) dma_step(1);
-  if (nsteps > 2) dma_step(2);
-  for (int st = 0; st < nsteps; ++st) {
-    // this wave's DMAs of step st have landed once at most the (up to two) newer steps' 4+4 remain outstanding
-    if (st + 2 < nsteps)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER_STEP) : "memory");
-    else if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP) : "memory");
-    else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // all ds_reads of step st-1 have returned (lgkmcnt) before anyone may refill its stage; then rendezvous:
-    // after the barrier every wave's part of step st is in LDS and stage (st-1)%4 is free.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (st + 3 < nsteps) dma_step(st + 3);              // refills the stage of step st-1
-    compute(st);
-  }
-  tile_epilogue<DT, BM, BN, WM, WN, LDS_BYTES>(p, acc, smem, m0, n0, bz, wm, wn, lane, wave);
-}
-
 // out = epi(sum over K-slices) for split-K launches: one thread per 8 consecutive columns of one row
 template <int DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) {
@@ -683,13 +568,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // K-loop variant choice (measured on MI355X, profiles/r01_diag_B18_*): LDS-DMA staging wins for dense GEMMs
 // (+5..18 % on K >= 1280, ~0 on K = 320); the conv gather is faster with the 2-deep register prefetch of variant 1
 // (its activation tile cannot use DMA).  IDF_GEMM_DMA=0/1 forces one variant for A/B runs.
-// IDF_GEMM_VARIANT=1|2|3 forces one K-loop variant for A/B runs (3 applies to dense GEMMs only; conv then uses 2).
+// IDF_GEMM_VARIANT=1|2 forces one K-loop variant for A/B runs.  Default: LDS-DMA (2) for dense GEMMs, register
+// prefetch (1) for the conv gather.  A third variant (4-stage ring of 32-deep K-steps, 3 DMA steps in flight, counted
+// vmcnt + raw s_barrier) was built and measured SLOWER than variant 2 on every shape but one (744 vs 846 TF at 8192^3,
+// 485 vs 644 at K=1280: a barrier per 8 MFMAs costs more than the deeper prefetch buys) and was removed; numbers in
+// profiles/r01_diag_B18_gemm_ring_vs_dma.log.
 inline int kloop_variant(bool conv) {
   static int v = -2;
   if (v == -2) { const char* e = getenv("IDF_GEMM_VARIANT"); v = e ? atoi(e) : -1; }
   if (v == 1 || v == 2) return v;
-  if (v == 3) return conv ? 2 : 3;
-  return conv ? 1 : 3;
+  return conv ? 1 : 2;
 }
 
 template <int DT, int BM, int BN, int WM, int WN, bool CONV>
@@ -697,13 +585,10 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
   const int variant = kloop_variant(CONV);
   void (*kern)(const CoreParams) = gemm_kernel<DT, BM, BN, WM, WN, CONV>;
   constexpr int cstage = 4 * WM * (WN + 4) * 4;
-  constexpr int kloop2 = 2 * (BM + BN) * 64 * 2, kloop3 = 4 * (BM + BN) * 32 * 2;
+  constexpr int kloop2 = 2 * (BM + BN) * 64 * 2;
   int smem = 2 * (BM + BN) * LSTR * 2;
   if (variant == 2) { kern = gemm_kernel_dma<DT, BM, BN, WM, WN, CONV>; smem = kloop2 > cstage ? kloop2 : cstage; }
-  if constexpr (!CONV) {
-    if (variant == 3) { kern = gemm_kernel_ring<DT, BM, BN, WM, WN>; smem = kloop3 > cstage ? kloop3 : cstage; }
-  }
-  static bool attr_set[4] = {false, false, false, false};
+  static bool attr_set[3] = {false, false, false};
   if (!attr_set[variant]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;

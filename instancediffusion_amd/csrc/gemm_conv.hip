@@ -314,17 +314,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const CoreParams p) {
     const unsigned short* Wl = Al + BM * LSTR;
     const unsigned short* af_base = Al + (wm * WM + l31) * LSTR + hi * 8;
     const unsigned short* wf_base = Wl + (wn * WN + l31) * LSTR + hi * 8;
+    // fragment reads of K-step ks+1 are issued BEFORE the MFMAs of K-step ks (register double-buffer), so the LDS
+    // latency (~100+ cycles) hides under 4-8 MFMAs instead of stalling every K-step (the compiler does not do this).
+    u32x4 wf[2][TN], af[2][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) wf[0][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * LSTR);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) af[0][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * LSTR);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      u32x4 wf[TN], af[TM];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BK / 16) {
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * LSTR + ks * 16);
+        for (int a = 0; a < TN; ++a) wf[nxt][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * LSTR + (ks + 1) * 16);
 #pragma unroll
-      for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * LSTR + ks * 16);
+        for (int b = 0; b < TM; ++b) af[nxt][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * LSTR + (ks + 1) * 16);
+      }
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[a], af[b], acc[a][b]);
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
     }
   };
 
@@ -510,18 +519,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_dma(const CoreParams p) {
     const unsigned short* Wl = Al + BM * RS;
     const unsigned short* af_base = Al + (wm * WM + l31) * RS;
     const unsigned short* wf_base = Wl + (wn * WN + l31) * RS;
+    u32x4 wf[2][TN], af[2][TM];                         // register double-buffered fragments (see variant 1)
+    {
+      const int slot = (hi ^ f_sw) * 8;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[0][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[0][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      const int slot = ((ks * 2 + hi) ^ f_sw) * 8;
-      u32x4 wf[TN], af[TM];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BK / 16) {
+        const int slot = (((ks + 1) * 2 + hi) ^ f_sw) * 8;
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
+        for (int a = 0; a < TN; ++a) wf[nxt][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
 #pragma unroll
-      for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
+        for (int b = 0; b < TM; ++b) af[nxt][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
+      }
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[a], af[b], acc[a][b]);
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
     }
   };
 

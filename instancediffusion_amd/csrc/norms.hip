@@ -96,21 +96,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
     sh[ch] = beta[ch] - mean[g] * w;
   }
   __syncthreads();
+  // Stream this block's row chunk with a FIXED channel chunk per thread (tx = 16-B column, ty = row lane): the 8
+  // scale/shift pairs live in registers for the whole row loop (the previous version re-read them from LDS per
+  // element with an 8-float lane stride: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.86).
   const int cpr = C >> 3;
-  const size_t total = (size_t)HW * cpr;                         // 16-B chunks in this batch element
+  const int TX = cpr < 256 ? cpr : 256;
+  const int TY = 256 / TX;
+  const int tx = tid % TX, ty = tid / TX;
+  const int rows_per = (HW + nblk_x - 1) / nblk_x;
+  const int r_begin = blockIdx.x * rows_per;
+  const int r_end = min(HW, r_begin + rows_per);
   const unsigned short* xb = x + (size_t)b * HW * C;
   unsigned short* ob = out + (size_t)b * HW * C;
-  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)nblk_x * 256) {
-    const int cc = (int)(i % cpr);
-    u32x4 v = *reinterpret_cast<const u32x4*>(xb + i * 8);
-    float f[8];
-    unpack8<DT>(v, f);
+  if (ty >= TY) return;
+  for (int cc = tx; cc < cpr; cc += TX) {
+    float scr[8], shr[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float y = fmaf(f[j], sc[cc * 8 + j], sh[cc * 8 + j]);
-      f[j] = silu ? silu_f(y) : y;
+    for (int j = 0; j < 8; ++j) { scr[j] = sc[cc * 8 + j]; shr[j] = sh[cc * 8 + j]; }
+    for (int r = r_begin + ty; r < r_end; r += TY) {
+      const size_t off = (size_t)r * C + cc * 8;
+      u32x4 v = *reinterpret_cast<const u32x4*>(xb + off);
+      float f[8];
+      unpack8<DT>(v, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float y = fmaf(f[j], scr[j], shr[j]);
+        f[j] = silu ? silu_f(y) : y;
+      }
+      *reinterpret_cast<u32x4*>(ob + off) = pack8<DT>(f);
     }
-    *reinterpret_cast<u32x4*>(ob + i * 8) = pack8<DT>(f);
   }
 }
 
@@ -196,8 +210,7 @@ extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const
   const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
   const size_t sm2 = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(float);
   if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
-  const size_t total = (size_t)HW * cpr;
-  int nblk = (int)((total + 256 * 4 - 1) / (256 * 4));          // >= 4 chunks (64 B) per thread
+  int nblk = (HW + TY * 8 - 1) / (TY * 8);                       // >= 8 rows per thread-row, <= 256 blocks per batch
   if (nblk < 1) nblk = 1;
   if (nblk > 256) nblk = 256;
   dim3 g1(nchunks, B), g2(nblk, B);

@@ -96,7 +96,8 @@ def _dist_worker(rank, world, port, q):
                               set_alpha_scale=set_alpha_scale, mis=meta["mis"])
     out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
                          guidance_scale=7.5)
-    q.put((rank, out.clone(), sampler.engine.ops.calls.get("attention", 0)))
+    # by value (numpy): a torch tensor would travel as a shared-memory handle that dies with this process
+    q.put((rank, out.numpy().copy(), sampler.engine.ops.calls.get("attention", 0)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -111,6 +112,7 @@ def test_mis_sharded_world2_gloo():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(o), n) for r, o, n in res]
     for p in procs:
         p.join(timeout=60)
     gold = cases.load_golden("tiny_box")

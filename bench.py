@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images-per-gpu", type=int, default=8)   # reference default --num_images 8 (README.md:122-132)
+    ap.add_argument("--max-units", type=int, default=36, help="MIS phase-1 (instance, image) units per batched forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -247,7 +248,7 @@ def main():
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
     _ = model.engine                                              # pack weights into HBM (bf16 GEMM images)
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=ALPHA_TYPE),
-                              set_alpha_scale=set_alpha_scale, mis=MIS)
+                              set_alpha_scale=set_alpha_scale, mis=MIS, max_units=args.max_units)
     shape = (n_images, 4, LATENT, LATENT)
 
     def one_step():

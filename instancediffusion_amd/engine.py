@@ -565,6 +565,24 @@ class UNetEngine:
             self._slot_bound[B] = cond.uid
         return slot
 
+    def gather_cond(self, bank: Cond, idx: torch.Tensor) -> Cond:
+        """Fill the static slot of batch size len(idx) with rows ``idx`` of ``bank`` (ONE gather per tensor, written
+        in place) and return the slot; ``forward_cond(x, t, slot)`` then replays the captured graph without any further
+        conditioning copy.  Used by the samplers to assemble [cond | uncond] / per-unit batches."""
+        B = int(idx.numel())
+        slot = self._slots.get(B)
+        if slot is None or len(slot._tensors()) != len(bank._tensors()) or any(
+                a.shape[1:] != b.shape[1:] for a, b in zip(slot._tensors(), bank._tensors())) or slot.n_ctx != bank.n_ctx:
+            slot = bank.select(idx)
+            self._slots[B] = slot
+            for k in [k for k in self._graphs if k[0] == B]:
+                del self._graphs[k]
+        else:
+            for dst, src in zip(slot._tensors(), bank._tensors()):
+                torch.index_select(src, 0, idx, out=dst)
+        self._slot_bound[B] = slot.uid
+        return slot
+
     def forward_cond(self, x: torch.Tensor, t: torch.Tensor, cond: Cond, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eps = UNet(x, t | cond).  The launch sequence is captured once per (batch, resolution, fuser on/off)
         into a hipGraph over static buffers and replayed; conditioning is copied into a static slot when it changes."""

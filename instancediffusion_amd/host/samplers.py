@@ -119,7 +119,11 @@ class PLMSSampler(_PLMSBase):
         img = img.to(dev, torch.float32)
         guided = uc is not None and guidance_scale != 1
         cond = self._cond(input)
-        pair = type(cond).cat([cond, self._uncond(uc)]) if guided else cond
+        if guided:
+            bank = type(cond).cat([cond, self._uncond(uc)])
+            pair = eng.gather_cond(bank, torch.arange(2 * b, device=dev))
+        else:
+            pair = cond
         time_range = np.flip(self.ddim_timesteps)
         total = self.ddim_timesteps.shape[0]
         alphas = self.alpha_generator_func(len(time_range)) if self.alpha_generator_func is not None else None
@@ -189,6 +193,15 @@ class PLMSSamplerInst(_PLMSBase):
         conds = [self._cond(inp) for inp in input_all]
         cond_u = self._uncond(uc) if guided else None
         CondT = type(conds[0])
+        # one bank of all conditionings; batches are assembled by a single row gather straight into the engine's
+        # static slot: row j*B + b = (instance j, image b), row n_all*B + b = unconditional of image b
+        bank = CondT.cat(conds + ([cond_u] if guided else []))
+
+        def rows(units):
+            r = [j * B + b for (j, b) in units]
+            if guided:
+                r += [n_all * B + b for (_, b) in units]
+            return torch.tensor(r, device=dev, dtype=torch.long)
 
         # ---------------- phase 1: N+1 independent trajectories per image (plms_instance.py:86-104) ----------
         # work unit = (instance j, image b), owned by rank (b + j) % world; the owner of image b (rank b % world)
@@ -209,9 +222,7 @@ class PLMSSamplerInst(_PLMSBase):
                 continue
             n = len(chunk)
             x = torch.stack([input_all[j]["x"][b] for (j, b) in chunk]).to(dev, torch.float32)
-            cc = CondT.cat([conds[j].select(torch.tensor([b], device=dev)) for (j, b) in chunk])
-            pair = CondT.cat([cc, CondT.cat([cond_u.select(torch.tensor([b], device=dev)) for (_, b) in chunk])]) \
-                if guided else cc
+            pair = eng.gather_cond(bank, rows(chunk))
             old: list = []
             for i, step in enumerate(time_range[:mis_step]):
                 self._apply_alpha(alphas, i)
@@ -253,8 +264,7 @@ class PLMSSamplerInst(_PLMSBase):
             x = merged[idx].contiguous()
             old = [torch.stack([eps_units[(0, b)][k] for b in mine]) for k in range(len(eps_units[(0, mine[0])]))] \
                 if mis_step > 0 else []
-            c0 = conds[0].select(idx)
-            pair = CondT.cat([c0, cond_u.select(idx)]) if guided else c0
+            pair = eng.gather_cond(bank, rows([(0, b) for b in mine]))
             for i, step in enumerate(time_range):
                 if i < mis_step:
                     continue

@@ -44,10 +44,13 @@ class HipOps:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _workspace(self, key, nfloats: int) -> torch.Tensor:
-        w = self._ws.get(key)
-        if w is None or w.numel() < nfloats:
+        """fp32 scratch keyed by (role, size): a buffer is NEVER reallocated or freed once handed out, because
+        captured hipGraphs keep its raw device pointer."""
+        k = (key, int(nfloats))
+        w = self._ws.get(k)
+        if w is None:
             w = torch.empty(int(nfloats), dtype=torch.float32, device=self.device)
-            self._ws[key] = w
+            self._ws[k] = w
         return w
 
     SPLITK_WS_BYTES = 256 << 20

@@ -229,18 +229,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+    # test hooks (1-GPU boxes): IDF_BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and IDF_DIST_BACKEND=gloo replaces
+    # RCCL, so the rank-sharded sampler + collectives can be exercised end-to-end without a multi-GPU node.
+    if os.environ.get("IDF_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" == RCCL on ROCm
+        backend = os.environ.get("IDF_DIST_BACKEND", "nccl")     # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    from oracle import ref_cpu                                    # only for DEFAULT_CFG + the cpu_baseline leg
     from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.config import SD15_BOX_CFG
     from instancediffusion_amd.host.diffusion import LatentDiffusion
     from instancediffusion_amd.host.samplers import PLMSSamplerInst
-    cfg = dict(ref_cpu.DEFAULT_CFG)
+    cfg = dict(SD15_BOX_CFG)
     model, sd = build_model(cfg)
     n_images = args.images_per_gpu * world
     inputs, uc, gi, host_inputs = make_inputs(cfg, n_images, dev)

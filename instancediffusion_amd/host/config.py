@@ -33,6 +33,13 @@ def load_yaml(path: str) -> Dict[str, Any]:
         return yaml.safe_load(f)
 
 
+# SD-1.5 InstanceDiffusion UNet + UniFusion hyper-parameters (reference configs/test_box.yaml:9-40), flat form
+SD15_BOX_CFG = dict(
+    in_channels=4, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1), num_res_blocks=2,
+    channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768, in_dim=768, out_dim=768, mid_dim=3072,
+    test_drop_boxes=False, test_drop_points=False, test_drop_scribbles=True, test_drop_masks=True)
+
+
 def unet_kwargs_from_cfg(cfg: Mapping[str, Any]) -> Dict[str, Any]:
     """Flat test/bench config (oracle-style keys) -> ``UNetModel`` constructor kwargs."""
     return dict(

@@ -8,11 +8,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from oracle import ref_cpu  # noqa: E402  (DEFAULT_CFG only)
+from instancediffusion_amd.host.config import SD15_BOX_CFG  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-cfg = dict(ref_cpu.DEFAULT_CFG)
+cfg = dict(SD15_BOX_CFG)
 model, sd = bench.build_model(cfg)
 dev = torch.device("cuda", 0)
 inputs, uc, gi, _ = bench.make_inputs(cfg, batch, dev)

@@ -157,7 +157,6 @@ def pmc_traffic(op_name, batch):
 def measure_roofline(engine, batch):
     """One instrumented eager forward at the phase-1 batch: per-kernel-family durations from HIP events."""
     dev = engine.device
-    from instancediffusion_amd.engine import Cond
     cond = engine._slots[batch]
     x = torch.randn(batch, 4, LATENT, LATENT, device=dev)
     t = torch.full((batch,), 500.0, device=dev)

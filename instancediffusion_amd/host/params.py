@@ -7,7 +7,7 @@ They have NO forward().
 from __future__ import annotations
 
 import math
-from typing import Dict, Sequence
+from typing import Dict
 
 import torch
 import torch.nn as nn

@@ -14,7 +14,7 @@ constructor / ``sample()`` API, same schedule, same update rule and quirks, diff
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -7,7 +7,6 @@ MI355X -- there is no CPU / eager fallback: calling ``forward`` without a GPU or
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, List, Optional
 
 import torch

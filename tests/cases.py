@@ -1,7 +1,6 @@
 """Shared test-case construction: regenerates exactly the inputs ``oracle/make_golden.py`` fed the reference."""
 from __future__ import annotations
 
-import json
 import os
 from typing import Dict
 

@@ -2,7 +2,6 @@
 (tests/emul_ops.EmulOps in fp32) on the same seeded inputs.  Tolerances are relative to the output max:
 bf16 storage, fp32 accumulation -> 2^-7 (one bf16 ulp of the largest element) unless stated; fp32 outputs 1e-5.
 """
-import math
 
 import pytest
 import torch

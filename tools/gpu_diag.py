@@ -3,7 +3,6 @@ Writes gpurun_out/diag.json.  Not a test: numbers guide kernel optimisation (fra
 import json
 import os
 import sys
-import time
 
 import torch
 

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidf_gfx950.so")
+LIB_PATH = os.environ.get("IDF_LIB_PATH", os.path.join(_HERE, "libidf_gfx950.so"))   # override: A/B builds only
 
 IDF_BF16, IDF_F16 = 0, 1
 EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \

@@ -32,8 +32,11 @@ struct AttnParams {
 // MFMASUM: d < 32*NMT, i.e. the O^T tile has spare rows -> row d of the V^T image is set to ONES so the softmax
 // denominator l = sum_j P[q][j] falls out of the PV MFMAs for free (no 32 VALU adds per tile per lane) and is rescaled
 // together with O.  (It then sums the 16-bit-rounded P, exactly the P that multiplies V.)
+#ifndef IDF_ATTN_MIN_WAVES
+#define IDF_ATTN_MIN_WAVES 1
+#endif
 template <int DT, int NKS, int NMT, bool MFMASUM>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn_kernel(const AttnParams p) {
   constexpr int KSTR = (2 * NKS + 1) * 8;          // K LDS row stride (elements): odd number of 16-B slots
   constexpr int KCH_MAX = (KVT * 2 * NKS + 255) / 256;
   constexpr int VCH_MAX = (NMT * 32 * 8 + 255) / 256;

@@ -640,8 +640,14 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
 template <int DT, bool CONV>
 int launch(const CoreParams& p, int batch, hipStream_t s) {
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
-  // tile choice: 128x128 when N fills it; 128(M) x 64(N) for N = 64 mod 128 (e.g. 320) or small N
-  if (geglu || (p.N % 128 == 0) || p.N > 1024) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
+  // tile choice: 128x128 when N fills it; 128(M) x 64(N) for N = 64 mod 128 (e.g. 320) or small N.  For the conv
+  // (long K = 9*Cin) the denser 64x64 wave tile wins even with a half-empty last column tile at Cout = 320
+  // (measured +15..18 %: 512 -> 602 and 596 -> 677 TF); for the short-K dense GEMMs it loses (378 -> 352 TF).
+  // IDF_TILE_WIDE=0/1 forces the choice for A/B runs.
+  static int wide = -2;
+  if (wide == -2) { const char* e = getenv("IDF_TILE_WIDE"); wide = e ? (e[0] == '1' ? 1 : 0) : -1; }
+  const bool use_wide = (wide >= 0) ? (wide == 1) : CONV;
+  if (geglu || (p.N % 128 == 0) || p.N > 1024 || (use_wide && p.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
   return launch_cfg<DT, 128, 64, 64, 32, CONV>(p, batch, s);
 }
 

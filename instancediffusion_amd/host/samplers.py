@@ -77,12 +77,14 @@ class _PLMSBase(object):
         t = torch.full((n,), float(step), device=x.device, dtype=torch.float32)
         return eng.forward_cond(x, t, cond_pair)
 
-    def _plms_step(self, x, old_eps: list, index: int, step: int, step_next: int, cond_pair, n, guided, gs):
-        """p_sample_plms (plms.py:117-167).  Returns (x_prev, e_t)."""
+    def _plms_step(self, x, old_eps: list, index: int, step: int, step_next: int, cond_pair, n, guided, gs,
+                   e_t_first=None):
+        """p_sample_plms (plms.py:117-167).  Returns (x_prev, e_t).  ``e_t_first``: guided eps of the first
+        evaluation when the caller already computed it (MIS start-of-trajectory de-duplication)."""
         ops = self.engine.ops
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
         s1m = float(self.ddim_sqrt_one_minus_alphas[index])
-        e_t = self._eps(x, step, cond_pair, n, guided, gs)
+        e_t = e_t_first if e_t_first is not None else self._eps(x, step, cond_pair, n, guided, gs)
         new = ops.empty(x.shape, torch.float32)
         if len(old_eps) == 0:
             x_pred = ops.plms_update(x, e_t, [], None, 0, a_t, a_prev, s1m, ops.empty(x.shape, torch.float32))
@@ -217,18 +219,39 @@ class PLMSSamplerInst(_PLMSBase):
             chunks = [units[k:k + self.max_units] for k in range(0, len(units), self.max_units)]
         x_units: Dict[tuple, torch.Tensor] = {}
         eps_units: Dict[tuple, list] = {}
+        same_start = all(inp["x"] is input_all[0]["x"] or torch.equal(inp["x"], input_all[0]["x"]) for inp in input_all[1:])
         for chunk in chunks:
             if not chunk:
                 continue
             n = len(chunk)
+            pair = None
             x = torch.stack([input_all[j]["x"][b] for (j, b) in chunk]).to(dev, torch.float32)
-            pair = eng.gather_cond(bank, rows(chunk))
             old: list = []
             for i, step in enumerate(time_range[:mis_step]):
                 self._apply_alpha(alphas, i)
                 index = total - i - 1
                 step_next = int(time_range[min(i + 1, len(time_range) - 1)])
-                x, e_t = self._plms_step(x, old, index, int(step), step_next, pair, n, guided, guidance_scale)
+                e_first = None
+                if i == 0 and guided and same_start:
+                    # Exact hoist: at the very first evaluation every instance trajectory of image b still holds the
+                    # SAME latent (the shared starting noise, inference.py:300-301) and the unconditional branch sees
+                    # only (x, t, uc, null grounding) -> it is identical for the N+1 instances of an image: evaluate it
+                    # once per image instead of once per (instance, image) unit.
+                    imgs = sorted({b for (_, b) in chunk})
+                    pos = {b: k for k, b in enumerate(imgs)}
+                    r = [j * B + b for (j, b) in chunk] + [n_all * B + b for b in imgs]
+                    slot = eng.gather_cond(bank, torch.tensor(r, device=dev, dtype=torch.long))
+                    xu = torch.stack([input_all[0]["x"][b] for b in imgs]).to(dev, torch.float32)
+                    xx = torch.cat([x, xu], 0)
+                    tt = torch.full((xx.shape[0],), float(step), device=dev, dtype=torch.float32)
+                    e2 = eng.forward_cond(xx, tt, slot, out=eng.buf("smp.eps_first", xx.shape, torch.float32))
+                    e_uc = e2[n:][torch.tensor([pos[b] for (_, b) in chunk], device=dev)]
+                    e_first = ops.cfg_combine(e2[:n].contiguous(), e_uc.contiguous(), guidance_scale,
+                                              ops.empty(x.shape, torch.float32))
+                if i == 0 or pair is None:
+                    pair = eng.gather_cond(bank, rows(chunk))
+                x, e_t = self._plms_step(x, old, index, int(step), step_next, pair, n, guided, guidance_scale,
+                                         e_t_first=e_first)
                 self._push(old, e_t)
             for k, u in enumerate(chunk):
                 x_units[u] = x[k]

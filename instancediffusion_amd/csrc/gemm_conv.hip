@@ -126,7 +126,11 @@ __device__ __forceinline__ void tile_epilogue(const CoreParams& p, f32x16 (&acc)
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(Cl + (b * 32 + l31) * CSTR + a * 32 + 8 * q + 4 * hi) =
             f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-  __syncthreads();
+  // No block barrier here: each wave reads back only ITS OWN staging region and a wave's LDS instructions execute in
+  // program order; the wave-level barrier only stops the COMPILER from hoisting the loads above the stores.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;

@@ -651,6 +651,12 @@ int launch(const CoreParams& p, int batch, hipStream_t s) {
   static int wide = -2;
   if (wide == -2) { const char* e = getenv("IDF_TILE_WIDE"); wide = e ? (e[0] == '1' ? 1 : 0) : -1; }
   const bool use_wide = (wide >= 0) ? (wide == 1) : CONV;
+  // IDF_TILE_SMALL=1 (A/B switch): 64x64 tiles (5 workgroups per CU) for short-K dense GEMMs, which are latency-bound
+  if constexpr (!CONV) {
+    static int small_t = -2;
+    if (small_t == -2) { const char* e = getenv("IDF_TILE_SMALL"); small_t = e ? atoi(e) : 0; }
+    if (small_t > 0 && !geglu && p.K <= small_t) return launch_cfg<DT, 64, 64, 32, 32, CONV>(p, batch, s);
+  }
   if (geglu || (p.N % 128 == 0) || p.N > 1024 || (use_wide && p.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
   return launch_cfg<DT, 128, 64, 64, 32, CONV>(p, batch, s);
 }

@@ -42,6 +42,16 @@ enum {
 int idf_abi_version(void);
 const char* idf_build_info(void);
 
+/* Kernel-selection knobs (process-global, for A/B measurement and for tests that must hit one specific kernel;
+ * results are identical up to fp32 summation order).  Returns the previous value, or IDF_E_ARG for an unknown knob.
+ *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256}-tile GEMM/conv kernel, 1 = automatic
+ *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default. */
+enum { IDF_TUNE_GEMM_BIG = 0 };
+int idf_set_tuning(int knob, int value);
+/* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
+enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0 };
+long long idf_get_stat(int stat);
+
 /* ---- GEMM: out[M,N] = epi( A[M,K] . W[N,K]^T ) ----------------------------------------------------------
  * Replaces F.linear / 1x1 nn.Conv2d call sites: attention.py:39,59,106-110,168-172,289,349-364;
  * openaimodel.py:199-205,222,360-364; text_grounding_net.py:73-81,293-298.

@@ -47,6 +47,8 @@ class AttnArgs(C.Structure):
 SYMBOLS = {
     "idf_abi_version": (ci, []),
     "idf_build_info": (C.c_char_p, []),
+    "idf_set_tuning": (ci, [ci, ci]),
+    "idf_get_stat": (ll, [ci]),
     "idf_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "idf_conv3x3": (ci, [C.POINTER(ConvArgs), vp]),
     "idf_conv_in": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),

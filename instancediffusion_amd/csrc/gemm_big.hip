@@ -1,0 +1,362 @@
+// gemm_big.hip -- K-loop variant 4: persistent big-tile MFMA GEMM / implicit-GEMM conv3x3 for gfx950.
+//
+// Why (measured on MI355X, profiles/r01_diag_B18_*): the 128x128 / 4-wave kernels of gemm_conv.hip top out at
+// ~870 TFLOP/s (35 % of the 2.5 PFLOP/s dense bf16 peak) and at ~400 on the K = 320 layers.  Two causes:
+//   * LDS: a 64x64 wave tile reads 4 fragments per 4 MFMAs and the 128x128 block tile stages 32 KB per 512 MFMA
+//     cycles -- the LDS pipe is as busy as the MFMA pipe;
+//   * a workgroup lives for only K/64 (= 5 for K = 320) K-tiles, so its prologue load latency, epilogue and launch
+//     ramp are paid per 1280 MFMA cycles.
+// This variant: ONE persistent 512-thread workgroup (8 wave64, 2 per SIMD) per CU walking 256 x BN output tiles
+// (BN = 320 or 256 -- every channel count of the SD-1.5 UNet is a multiple of 320, every GEGLU width of 256);
+// wave tile 64 x BN/2 (7 or 6 fragment reads per 10 or 8 MFMAs); both operand tiles staged by LDS-DMA
+// (global_load_lds_dwordx4) into a 2-stage ring of 72 KB stages; the K-tile stream is FLATTENED across output tiles,
+// so the first K-tile of the next tile is in flight during the last MFMAs and the epilogue of the current one.
+// The conv3x3 activation gather also uses LDS-DMA: a lane whose tap falls in the zero padding points its source
+// address at a 128-B page of zeros instead of masking a register.
+// Epilogue: entirely in registers.  GEGLU pairs are combined first (value and gate accumulators of one output sit in the
+// same lane); v_permlane32_swap then exchanges register pairs between the two lane halves so that a lane owns 16
+// consecutive columns of its row: 16-B stores / residual / rowbias accesses without an LDS transposition or a barrier.
+//
+// Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops 2*M*N*K.  LDS image and XOR swizzle are the ones
+// of gemm_kernel_dma (linear 128-B rows, 16-B slot ^= (row >> 1) & 7 applied on the global source address).
+#include "gemm_core.h"
+#include <cstdlib>
+
+using namespace idfcore;
+
+namespace {
+
+__device__ __attribute__((aligned(128))) unsigned short idf_zero_page[64];   // zero-initialised device memory
+
+constexpr int BM = 256, WM = 64, TM = 2, RS = 64;
+constexpr int STAGE = 36864;                 // elements per pipeline stage: 73728 B = (256+320)*64*2
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, int STEP, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IC<I>{}); static_for<I + STEP, N, STEP>(f); }
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int DT, int BN, bool CONV>
+__global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
+  constexpr int WN = BN / 2, TN = WN / 32;
+  constexpr int W_INST = BN / 64, A_INST = BM / 64;        // LDS-DMA instructions (8 rows x 128 B each) per wave per K-tile
+  static_assert((BM + BN) * RS <= STAGE, "stage too small");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int G = gridDim.x;
+  // XCD-aware order: workgroup L runs on XCD L % 8; within one round of G tiles XCD x takes the CONTIGUOUS tiles
+  // [x*G/8, (x+1)*G/8) of the n-fastest list, so tiles sharing an activation m-tile / weight n-tile share an L2.
+  const int slot = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tiles_n = p.N / BN;
+  const int nk = p.K / BK;
+
+  // ---------------- loader state (runs one K-tile ahead of the MFMAs, across output-tile boundaries)
+  const int dr = lane >> 3, dc = lane & 7;
+  unsigned woff[W_INST], aoff[A_INST];
+  int ayx[A_INST];                                        // conv: (yo*stride-1) << 16 | (xo*stride-1) & 0xffff
+  int l_seq, l_kt = 0, tap = 0, ci0 = 0;
+
+  auto setup_loader = [&](int tile) {
+    const int m_tile = tile / tiles_n;
+    const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
+#pragma unroll
+    for (int j = 0; j < W_INST; ++j) {
+      const int row = 8 * (wave + 8 * j) + dr;
+      woff[j] = (unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)((dc ^ ((row >> 1) & 7)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < A_INST; ++j) {
+      const int row = 8 * (wave + 8 * j) + dr;
+      const int m = min(m0 + row, p.M - 1);
+      const unsigned sw = (unsigned)((dc ^ ((row >> 1) & 7)) * 8);
+      if (CONV) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, rem = m - b * hw;
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        ayx[j] = ((yo * p.stride - 1) << 16) | ((xo * p.stride - 1) & 0xffff);
+        aoff[j] = (unsigned)b * (unsigned)(p.Hin * p.Win) * (unsigned)p.lda + sw;
+      } else {
+        ayx[j] = 0;
+        aoff[j] = (unsigned)m * (unsigned)p.lda + sw;
+      }
+    }
+    tap = 0; ci0 = 0;
+  };
+
+  auto issue_dma = [&](int stage) {                       // enqueue K-tile l_kt of tile l_seq into `stage`, then advance
+    unsigned short* Al = smem + stage * STAGE;
+    unsigned short* Wl = Al + BM * RS;
+    const unsigned short* Wk = p.W + (size_t)l_kt * BK;
+#pragma unroll
+    for (int j = 0; j < W_INST; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wk + woff[j]), (lptr_t)(Wl + 8 * (wave + 8 * j) * RS), 16, 0, 0);
+    if (CONV) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+      const unsigned short* Ak = p.A + ci0;
+#pragma unroll
+      for (int j = 0; j < A_INST; ++j) {
+        const int yi = (ayx[j] >> 16) + ky, xi = (int)(short)(ayx[j] & 0xffff) + kx;
+        const bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
+        const int ys = yi >> p.up, xs = xi >> p.up;
+        const unsigned short* src = ok ? Ak + (aoff[j] + (unsigned)(ys * p.Win + xs) * (unsigned)p.lda)
+                                       : idf_zero_page + dc * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Al + 8 * (wave + 8 * j) * RS), 16, 0, 0);
+      }
+      ci0 += BK;
+      if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
+    } else {
+      const unsigned short* Ak = p.A + (size_t)l_kt * BK;
+#pragma unroll
+      for (int j = 0; j < A_INST; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ak + aoff[j]), (lptr_t)(Al + 8 * (wave + 8 * j) * RS), 16, 0, 0);
+    }
+    if (++l_kt == nk) {
+      l_kt = 0;
+      l_seq += G;
+      if (l_seq < tiles_total) setup_loader(l_seq);
+    }
+  };
+
+  // ---------------- MFMA side
+  f32x16 acc[TN][TM];
+  const int f_sw = (l31 >> 1) & 7;
+  auto compute = [&](int stage) {
+    const unsigned short* Al = smem + stage * STAGE;
+    const unsigned short* Wl = Al + BM * RS;
+    const unsigned short* af_base = Al + (wm * WM + l31) * RS;
+    const unsigned short* wf_base = Wl + (wn * WN + l31) * RS;
+    u32x4 wf[2][TN], af[2][TM];                           // register double-buffered fragments
+    {
+      const int s8 = (hi ^ f_sw) * 8;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[0][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + s8);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[0][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + s8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BK / 16) {
+        const int s8 = (((ks + 1) * 2 + hi) ^ f_sw) * 8;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[nxt][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + s8);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) af[nxt][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + s8);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
+    }
+  };
+
+  int seq = slot;
+  if (seq >= tiles_total) return;
+  l_seq = seq;
+  setup_loader(l_seq);
+  issue_dma(0);
+  int it = 0;
+  const int epi = p.epi;
+  const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+
+  for (; seq < tiles_total; seq += G) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's
+      // vmcnt wait followed by a barrier (hipcc does not add the wait to a barrier at the loop head by itself)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                    // ... and every wave has finished reading stage (it+1)&1
+      if (l_seq < tiles_total) issue_dma((it + 1) & 1);
+      compute(it & 1);
+      ++it;
+    }
+    // ---------------- epilogue of tile seq: no LDS, no barrier -- a wave that finishes its MFMAs early runs its epilogue
+    // while the other wave of its SIMD is still in the K-loop.
+    // acc[a][b][4q+e] = D[n = a*32 + 8q + 4hi + e][m = b*32 + l31].  Two v_permlane32_swap per register pair
+    // (q0 <-> q2, q1 <-> q3 between the lane halves) leave every lane with 16 CONSECUTIVE columns of its row:
+    // n = a*32 + 16*hi + [0,16)  ->  two 16-B stores per (a, b), 16-B residual / rowbias loads, float4 bias loads.
+    const int m_tile = seq / tiles_n;
+    const int n0 = (seq - m_tile * tiles_n) * BN, m0 = m_tile * BM;
+    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    auto swap16 = [&](const f32x16& c, float* v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[e]), __float_as_uint(c[8 + e]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[4 + e]), __float_as_uint(c[12 + e]), false, false);
+        v[e] = __uint_as_float(s02[0]); v[4 + e] = __uint_as_float(s02[1]);
+        v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
+      }
+    };
+    if (epi & IDF_EPI_GEGLU) {
+      if constexpr ((TN & 1) == 0) {
+        static_for<0, TN, 2>([&](auto AI) {
+          constexpr int a = decltype(AI)::value;
+          const int npk = nw + a * 32;                    // packed weight rows: [32 value | 32 gate]
+          f32x4 bv[4], bg[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bv[q] = *reinterpret_cast<const f32x4*>(p.bias + npk + 8 * q + 4 * hi);
+            bg[q] = *reinterpret_cast<const f32x4*>(p.bias + npk + 32 + 8 * q + 4 * hi);
+          }
+#pragma unroll
+          for (int b = 0; b < TM; ++b) {
+            f32x16 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                o[4 * q + e] = (acc[a][b][4 * q + e] + bv[q][e]) * gelu_erf_f(acc[a + 1][b][4 * q + e] + bg[q][e]);
+            float v[16];
+            swap16(o, v);
+            const int m = mw + b * 32 + l31;
+            if (m < p.M) {
+              unsigned short* op = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + (npk >> 1) + 16 * hi;
+              *reinterpret_cast<u32x4*>(op) = pack8<DT>(v);
+              *reinterpret_cast<u32x4*>(op + 8) = pack8<DT>(v + 8);
+            }
+          }
+        });
+      }
+    } else {
+      static_for<0, TN, 1>([&](auto AI) {
+        constexpr int a = decltype(AI)::value;
+        const int n = nw + a * 32 + 16 * hi;
+        f32x4 bs[4];
+        if (epi & IDF_EPI_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bs[j] = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * j);
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          float v[16];
+          swap16(acc[a][b], v);
+          const int m = mw + b * 32 + l31;
+          if (m >= p.M) continue;
+          if (epi & IDF_EPI_BIAS) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] += bs[j >> 2][j & 3];
+          }
+          if (epi & IDF_EPI_ROWBIAS) {
+            const unsigned short* rb = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n;
+            float r[16];
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(rb), r);
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(rb + 8), r + 8);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] += r[j];
+          }
+          if (epi & IDF_EPI_SILU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = silu_f(v[j]);
+          }
+          if (epi & IDF_EPI_GELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = gelu_erf_f(v[j]);
+          }
+          if (epi & IDF_EPI_RES) {
+            const unsigned short* rr = p.res + (size_t)m * p.ldr + n;
+            const float gm = (epi & IDF_EPI_GATE) ? gate : 1.0f;
+            float r[16];
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(rr), r);
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(rr + 8), r + 8);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = fmaf(gm, v[j], r[j]);
+          }
+          if (epi & IDF_EPI_OUT_F32) {
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + 4 * j) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+          } else {
+            unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + n;
+            *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
+            *reinterpret_cast<u32x4*>(o + 8) = pack8<DT>(v + 8);
+          }
+        }
+      });
+    }
+  }
+}
+
+int g_num_cu = 0;
+
+template <int DT, int BN, bool CONV>
+int launch_big_cfg(const CoreParams& p, hipStream_t s) {
+  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BN, CONV>;
+  constexpr int smem = 2 * STAGE * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cu = n;
+  }
+  CoreParams q = p;
+  q.splitk = 1; q.kt_per_slice = p.K / BK;
+  const int tiles = (p.N / BN) * ((p.M + BM - 1) / BM);
+  const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, q, tiles);
+  return idf_launch_status();
+}
+
+}  // namespace
+
+long long idf_stat_big_launches = 0;
+
+// Shape gate + tile-width choice.  `force` (IDF_GEMM_VARIANT=4) skips the occupancy heuristic, not the shape rules.
+int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s) {
+  const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
+  if (p.K < 2 * BK || (p.K % BK) != 0) return IDF_BIG_UNSUPPORTED;
+  if (p.epi & IDF_EPI_OUT_NCHW) return IDF_BIG_UNSUPPORTED;
+  if (p.n_valid != p.N) return IDF_BIG_UNSUPPORTED;
+  if ((p.lda % 8) || (p.ldw % 8)) return IDF_BIG_UNSUPPORTED;
+  // the in-register epilogue uses 16-B vector accesses only
+  if ((p.ldo % 8) || ((p.epi & IDF_EPI_RES) && (p.ldr % 8)) || ((p.epi & IDF_EPI_ROWBIAS) && (p.ld_rowbias % 8))) return IDF_BIG_UNSUPPORTED;
+  if (!aligned16(p.out) || ((p.epi & IDF_EPI_RES) && !aligned16(p.res)) || ((p.epi & IDF_EPI_ROWBIAS) && !aligned16(p.rowbias)) ||
+      ((p.epi & (IDF_EPI_BIAS | IDF_EPI_GEGLU)) && !aligned16(p.bias))) return IDF_BIG_UNSUPPORTED;
+  int bn = 0;
+  if (geglu) bn = (p.N % 256 == 0) ? 256 : 0;
+  else if (p.N % 320 == 0) bn = 320;
+  else if (p.N % 256 == 0) bn = 256;
+  if (!bn) return IDF_BIG_UNSUPPORTED;
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cu = n;
+  }
+  const long long tiles = (long long)(p.N / bn) * ((p.M + BM - 1) / BM);
+  if (!force) {
+    // tile quantisation: one persistent workgroup per CU processes ceil(tiles / CUs) tiles
+    const long long rounds = (tiles + g_num_cu - 1) / g_num_cu;
+    const double eff = (double)tiles / (double)(rounds * g_num_cu);
+    if (eff < 0.80) return IDF_BIG_UNSUPPORTED;
+  }
+  {                                                       // the loader uses 32-bit element offsets
+    const unsigned long long rows = conv ? (unsigned long long)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win : (unsigned long long)p.M;
+    if (rows * (unsigned long long)p.lda >= (1ull << 31) || (unsigned long long)p.N * p.ldw >= (1ull << 31)) return IDF_BIG_UNSUPPORTED;
+  }
+  ++idf_stat_big_launches;
+#define IDF_BIG_DISPATCH(DT)                                                                                   \
+  if (conv) return bn == 320 ? launch_big_cfg<DT, 320, true>(p, s) : launch_big_cfg<DT, 256, true>(p, s);      \
+  return bn == 320 ? launch_big_cfg<DT, 320, false>(p, s) : launch_big_cfg<DT, 256, false>(p, s);
+  if (dtype == IDF_BF16) { IDF_BIG_DISPATCH(IDF_BF16) }
+  if (dtype == IDF_F16) { IDF_BIG_DISPATCH(IDF_F16) }
+#undef IDF_BIG_DISPATCH
+  return IDF_E_UNSUPPORTED;
+}

@@ -8,101 +8,17 @@
 // output columns of one output row: epilogue = 8-byte packed stores, float4 bias loads, in-register GEGLU.
 //
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops = 2*M*N*K.
-#include "common.h"
+#include "gemm_core.h"
 #include <cstdlib>
+
+using namespace idfcore;
 
 namespace {
 
-struct CoreParams {
-  const unsigned short* W; int ldw; long long strideW; int N;
-  const unsigned short* A; int lda; long long strideA; int M; int K;
-  int Hin, Win, Cin, Ho, Wo, stride, up;           // conv gather
-  void* out; int ldo; long long strideO;
-  const float* bias; const unsigned short* rowbias; int ld_rowbias; int rows_per_batch;
-  const unsigned short* res; int ldr; long long strideR;
-  const float* gate; int epi; int n_valid;
-  float* ws; size_t ws_bytes; int splitk; int kt_per_slice;   // split-K: fp32 partial slabs ws[slice][M][N]
-};
-
-constexpr int BK = 64;
+#ifndef IDF_GEMM_BIG_DEFAULT
+#define IDF_GEMM_BIG_DEFAULT 1
+#endif
 constexpr int LSTR = 72;   // LDS row stride in elements (144 B)
-
-// Epilogue for 8 consecutive output columns n..n+7 of row m (n % 8 == 0).  Shared by the main kernel (after the
-// accumulators were transposed through LDS so that a lane owns a contiguous 8-column run -> 16-B coalesced residual /
-// rowbias loads and FULL-LINE 16-B stores) and by the split-K reducer.
-template <int DT>
-__device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, int n, float* v, float gate) {
-  const int epi = p.epi;
-  const bool full = (n + 7 < p.N);
-  if (epi & IDF_EPI_BIAS) {
-    if (full) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
-    }
-  }
-  if (epi & IDF_EPI_ROWBIAS) {
-    const unsigned short* rb = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n;
-    if (full && ((p.ld_rowbias & 7) == 0)) {
-      float r[8];
-      unpack8<DT>(*reinterpret_cast<const u32x4*>(rb), r);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += r[e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
-    }
-  }
-  if (epi & IDF_EPI_SILU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-  }
-  if (epi & IDF_EPI_GELU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-  }
-  if (epi & IDF_EPI_RES) {
-    const unsigned short* rr = p.res + (size_t)bz * p.strideR + (size_t)m * p.ldr + n;
-    const float gm = (epi & IDF_EPI_GATE) ? gate : 1.0f;
-    if (full && ((p.ldr & 7) == 0)) {
-      float r[8];
-      unpack8<DT>(*reinterpret_cast<const u32x4*>(rr), r);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaf(gm, v[e], r[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] = fmaf(gm, v[e], Elem<DT>::to_f32(rr[e]));
-    }
-  }
-  if (epi & IDF_EPI_OUT_NCHW) {
-    const int hw = p.Ho * p.Wo;
-    const int bb = m / hw, rem = m - bb * hw;
-    float* o = reinterpret_cast<float*>(p.out);
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (n + e < p.n_valid) o[((size_t)bb * p.n_valid + (n + e)) * hw + rem] = v[e];
-  } else if (epi & IDF_EPI_OUT_F32) {
-    float* o = reinterpret_cast<float*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
-    if (full && ((p.ldo & 3) == 0)) {
-      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = v[e];
-    }
-  } else {
-    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
-    if (full && ((p.ldo & 7) == 0)) {
-      *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
-    }
-  }
-}
 
 // Tile epilogue shared by both K-loop variants (see the comment inside).
 template <int DT, int BM, int BN, int WM, int WN, int KLOOP_LDS_BYTES>
@@ -596,6 +512,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // vmcnt + raw s_barrier) was built and measured SLOWER than variant 2 on every shape but one (744 vs 846 TF at 8192^3,
 // 485 vs 644 at K=1280: a barrier per 8 MFMAs costs more than the deeper prefetch buys) and was removed; numbers in
 // profiles/r01_diag_B18_gemm_ring_vs_dma.log.
+int g_big_mode = -2;
+inline int gemm_big_mode() {
+  if (g_big_mode == -2) { const char* e = getenv("IDF_GEMM_BIG"); g_big_mode = e ? atoi(e) : IDF_GEMM_BIG_DEFAULT; }
+  return g_big_mode;
+}
+
 inline int kloop_variant(bool conv) {
   static int v = -2;
   if (v == -2) { const char* e = getenv("IDF_GEMM_VARIANT"); v = e ? atoi(e) : -1; }
@@ -651,17 +573,34 @@ int launch(const CoreParams& p, int batch, hipStream_t s) {
   static int wide = -2;
   if (wide == -2) { const char* e = getenv("IDF_TILE_WIDE"); wide = e ? (e[0] == '1' ? 1 : 0) : -1; }
   const bool use_wide = (wide >= 0) ? (wide == 1) : CONV;
-  // IDF_TILE_SMALL=1 (A/B switch): 64x64 tiles (5 workgroups per CU) for short-K dense GEMMs, which are latency-bound
-  if constexpr (!CONV) {
-    static int small_t = -2;
-    if (small_t == -2) { const char* e = getenv("IDF_TILE_SMALL"); small_t = e ? atoi(e) : 0; }
-    if (small_t > 0 && !geglu && p.K <= small_t) return launch_cfg<DT, 64, 64, 32, 32, CONV>(p, batch, s);
+  // K-loop variant 4 (gemm_big.hip): persistent 256 x {320,256} tiles.  IDF_GEMM_BIG=0 off, 1 auto (shape + tile
+  // quantisation heuristic), 2 forced whenever the shape qualifies.
+  const int big = gemm_big_mode();
+  if (big > 0 && batch == 1) {
+    const int rc = idf_launch_big(p, DT, CONV, big == 2, s);
+    if (rc != IDF_BIG_UNSUPPORTED) return rc;
   }
+  // (64x64 tiles for short-K dense GEMMs were measured 6-20 % slower: profiles/r01_diag_B18_tile64_ab.log)
   if (geglu || (p.N % 128 == 0) || p.N > 1024 || (use_wide && p.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
   return launch_cfg<DT, 128, 64, 64, 32, CONV>(p, batch, s);
 }
 
 }  // namespace
+
+extern "C" int idf_set_tuning(int knob, int value) {
+  if (knob == IDF_TUNE_GEMM_BIG) {
+    if (value < 0 || value > 2) return IDF_E_ARG;
+    const int prev = gemm_big_mode();
+    g_big_mode = value;
+    return prev;
+  }
+  return IDF_E_ARG;
+}
+
+extern "C" long long idf_get_stat(int stat) {
+  if (stat == IDF_STAT_GEMM_BIG_LAUNCHES) return idf_stat_big_launches;
+  return -1;
+}
 
 extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W || !a->out) return IDF_E_ARG;

@@ -1,0 +1,104 @@
+// gemm_core.h -- pieces shared by the MFMA GEMM / implicit-GEMM conv translation units (gemm_conv.hip, gemm_big.hip):
+// the launch parameter block, the K-tile depth and the 8-column epilogue.
+#pragma once
+#include "common.h"
+
+namespace idfcore {
+
+struct CoreParams {
+  const unsigned short* W; int ldw; long long strideW; int N;
+  const unsigned short* A; int lda; long long strideA; int M; int K;
+  int Hin, Win, Cin, Ho, Wo, stride, up;           // conv gather
+  void* out; int ldo; long long strideO;
+  const float* bias; const unsigned short* rowbias; int ld_rowbias; int rows_per_batch;
+  const unsigned short* res; int ldr; long long strideR;
+  const float* gate; int epi; int n_valid;
+  float* ws; size_t ws_bytes; int splitk; int kt_per_slice;   // split-K: fp32 partial slabs ws[slice][M][N]
+};
+
+constexpr int BK = 64;
+
+// Epilogue for 8 consecutive output columns n..n+7 of row m (n % 8 == 0).  Shared by the main kernel (after the
+// accumulators were transposed through LDS so that a lane owns a contiguous 8-column run -> 16-B coalesced residual /
+// rowbias loads and FULL-LINE 16-B stores) and by the split-K reducer.
+template <int DT>
+__device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, int n, float* v, float gate) {
+  const int epi = p.epi;
+  const bool full = (n + 7 < p.N);
+  if (epi & IDF_EPI_BIAS) {
+    if (full) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+    }
+  }
+  if (epi & IDF_EPI_ROWBIAS) {
+    const unsigned short* rb = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n;
+    if (full && ((p.ld_rowbias & 7) == 0)) {
+      float r[8];
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(rb), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += Elem<DT>::to_f32(rb[e]);
+    }
+  }
+  if (epi & IDF_EPI_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+  }
+  if (epi & IDF_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+  }
+  if (epi & IDF_EPI_RES) {
+    const unsigned short* rr = p.res + (size_t)bz * p.strideR + (size_t)m * p.ldr + n;
+    const float gm = (epi & IDF_EPI_GATE) ? gate : 1.0f;
+    if (full && ((p.ldr & 7) == 0)) {
+      float r[8];
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(rr), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(gm, v[e], r[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] = fmaf(gm, v[e], Elem<DT>::to_f32(rr[e]));
+    }
+  }
+  if (epi & IDF_EPI_OUT_NCHW) {
+    const int hw = p.Ho * p.Wo;
+    const int bb = m / hw, rem = m - bb * hw;
+    float* o = reinterpret_cast<float*>(p.out);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (n + e < p.n_valid) o[((size_t)bb * p.n_valid + (n + e)) * hw + rem] = v[e];
+  } else if (epi & IDF_EPI_OUT_F32) {
+    float* o = reinterpret_cast<float*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+    if (full && ((p.ldo & 3) == 0)) {
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = v[e];
+    }
+  } else {
+    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + n;
+    if (full && ((p.ldo & 7) == 0)) {
+      *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) o[e] = Elem<DT>::from_f32(v[e]);
+    }
+  }
+}
+
+
+}  // namespace idfcore
+
+// Big-tile persistent kernel (gemm_big.hip).  Returns IDF_BIG_UNSUPPORTED when the shape does not qualify.
+#define IDF_BIG_UNSUPPORTED (-100)
+extern long long idf_stat_big_launches;
+int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s);

@@ -348,3 +348,123 @@ def test_convnext_pieces(ops, ref):
     torch.cuda.synchronize()
     assert relmax(buf[:, :96], ref.layernorm(x2.float(), torch.empty(100, 96), gm, bt, 1e-6)) < BF16_TOL
     assert float(buf[:, 96:].float().abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# persistent big-tile GEMM / conv kernel (gemm_big.hip), forced through idf_set_tuning
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def big():
+    """Force the 256 x {320,256}-tile kernel for every qualifying shape; yields a callable returning how many launches
+    it served since the fixture started (so a test cannot pass on the 128x128 kernels by accident)."""
+    from instancediffusion_amd import _lib
+    lib = _lib.load()
+    prev = lib.idf_set_tuning(0, 2)
+    start = lib.idf_get_stat(0)
+    yield lambda: lib.idf_get_stat(0) - start
+    lib.idf_set_tuning(0, prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (4113, 640, 1280), (300, 512, 256), (256, 1280, 128),
+                                   (33280, 640, 320), (66560 + 5, 320, 192)])
+def test_gemm_big_bias(ops, big, M, N, K):
+    a, w, b = to16(gen((M, K), 1)), to16(gen((N, K), 2, K ** -0.5)), gen((N,), 3)
+    want = a.float() @ w.float().t() + b
+    out = ops.gemm(dev(a), dev(w), ops.empty((M, N)), bias=dev(b))
+    torch.cuda.synchronize()
+    assert big() == 1
+    assert relmax(out, want) < BF16_TOL
+
+
+def test_gemm_big_matches_small_kernel_bitwise_on_exact_data(ops, big):
+    """Integer-valued operands: every partial sum is exact in fp32, so both kernels must agree bit for bit."""
+    from instancediffusion_amd import _lib
+    M, N, K = 70000, 960, 320
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+    w = torch.randint(-4, 5, (N, K), generator=g).to(torch.bfloat16)
+    o_big = ops.gemm(dev(a), dev(w), ops.empty((M, N)))
+    torch.cuda.synchronize()
+    assert big() == 1
+    _lib.load().idf_set_tuning(0, 0)
+    o_small = ops.gemm(dev(a), dev(w), ops.empty((M, N)))
+    torch.cuda.synchronize()
+    _lib.load().idf_set_tuning(0, 2)
+    assert big() == 1
+    assert torch.equal(o_big, o_small)
+    assert torch.equal(o_big.float().cpu(), (a.float() @ w.float().t()).to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("act", [None, "silu", "gelu"])
+def test_gemm_big_epilogues(ops, big, act):
+    M, N, K = 1300, 640, 320
+    a, w, b = to16(gen((M, K), 4)), to16(gen((N, K), 5, K ** -0.5)), gen((N,), 6)
+    res = to16(gen((M, N), 7))
+    rowb = to16(gen((4, N), 8))
+    gate = torch.tensor([0.37])
+    acc = a.float() @ w.float().t() + b + rowb.float()[torch.arange(M) // 325]
+    if act == "silu":
+        acc = torch.nn.functional.silu(acc)
+    elif act == "gelu":
+        acc = torch.nn.functional.gelu(acc)
+    want = res.float() + 0.37 * acc
+    out = ops.gemm(dev(a), dev(w), ops.empty((M, N)), bias=dev(b), rowbias=dev(rowb), rows_per_batch=325,
+                   res=dev(res), gate=dev(gate), act=act)
+    torch.cuda.synchronize()
+    assert relmax(out, want) < BF16_TOL
+    buf = dev(res.clone())                                   # in-place residual
+    ops.gemm(dev(a), dev(w), buf, bias=dev(b), res=buf)
+    out32 = ops.gemm(dev(a), dev(w), ops.empty((M, N), torch.float32))
+    torch.cuda.synchronize()
+    assert big() == 3
+    assert relmax(buf, res.float() + a.float() @ w.float().t() + b) < BF16_TOL
+    assert relmax(out32, a.float() @ w.float().t()) < 1e-5
+
+
+@pytest.mark.parametrize("M,C", [(700, 320), (2100, 640)])
+def test_gemm_big_geglu(ops, big, M, C):
+    from instancediffusion_amd.engine import pack_geglu
+    a = to16(gen((M, C), 9))
+    w, b = gen((8 * C, C), 10, C ** -0.5), gen((8 * C,), 11)
+    w16 = to16(w)
+    h = a.float() @ w16.float().t() + b
+    x, g = h.chunk(2, -1)
+    want = x * torch.nn.functional.gelu(g)
+    wp, bp = pack_geglu(w16.float(), b)
+    out = ops.gemm(dev(a), dev(to16(wp)), ops.empty((M, 4 * C)), bias=dev(bp), geglu=True)
+    torch.cuda.synchronize()
+    assert big() == 1
+    assert relmax(out, want) < BF16_TOL
+
+
+def test_gemm_big_f16(big):
+    from instancediffusion_amd.ops import HipOps
+    o16 = HipOps(torch.float16)
+    M, N, K = 777, 320, 640
+    a, w = gen((M, K), 31).half(), gen((N, K), 32, K ** -0.5).half()
+    out = o16.gemm(dev(a), dev(w), o16.empty((M, N)))
+    torch.cuda.synchronize()
+    assert big() == 1
+    assert relmax(out, a.float() @ w.float().t()) < 2.0 ** -10
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [
+    (2, 16, 16, 128, 320, 1, 0), (3, 16, 16, 64, 640, 2, 0), (1, 8, 8, 128, 320, 1, 1), (1, 12, 20, 192, 256, 1, 0),
+    (1, 7, 9, 64, 320, 2, 0), (5, 64, 64, 320, 320, 1, 0)])
+def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
+    from instancediffusion_amd.engine import pack_conv3x3
+    x = to16(gen((B, H, W, Cin), 20))
+    w4 = gen((Cout, Cin, 3, 3), 21, (9 * Cin) ** -0.5)
+    b = gen((Cout,), 22)
+    wp = to16(pack_conv3x3(w4))
+    Ho = ((H << up) - 1) // stride + 1
+    Wo = ((W << up) - 1) // stride + 1
+    rowb = to16(gen((B, Cout), 23))
+    res = to16(gen((B, Ho, Wo, Cout), 24))
+    want = ref.conv3x3(x.float(), wp.float(), torch.empty(B, Ho, Wo, Cout), bias=b, rowbias=rowb.float(),
+                       res=res.float(), stride=stride, upsample=up)
+    out = ops.conv3x3(dev(x), dev(wp), ops.empty((B, Ho, Wo, Cout)), bias=dev(b), rowbias=dev(rowb), res=dev(res),
+                      stride=stride, upsample=up)
+    torch.cuda.synchronize()
+    assert big() == 1
+    assert relmax(out, want) < BF16_TOL

@@ -218,8 +218,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images-per-gpu", type=int, default=8)   # reference default --num_images 8 (README.md:122-132)
-    ap.add_argument("--max-units", type=int, default=36, help="MIS phase-1 (instance, image) units per batched forward")
+    ap.add_argument("--images-per-gpu", type=int, default=32)  # 32 images x (8+1) trajectories x cond/uncond = 9 forwards of 64 rows per MIS step
+    ap.add_argument("--max-units", type=int, default=32, help="MIS phase-1 (instance, image) units per batched forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -50,6 +50,17 @@ for (M, N, K, tag) in [(B * 4096, 320, 320, "proj 64^2"), (B * 4096, 640, 320, "
     a, w, o = rnd(M, K), rnd(N, K), ops.empty((M, N))
     rec(f"gemm {tag} M{M} N{N} K{K}", timeit(lambda: ops.gemm(a, w, o)), flops=2.0 * M * N * K)
 
+# epilogue cost on the short-K layers: same GEMM with bias+residual, and the packed GEGLU
+if os.environ.get("DIAG_EPI", "1") == "1":
+    for (M, N, K, tag) in [(B * 4096, 320, 320, "proj 64^2"), (B * 1024, 640, 640, "proj 32^2")]:
+        a, w, o = rnd(M, K), rnd(N, K), ops.empty((M, N))
+        bias, resid = torch.randn(N, device="cuda"), rnd(M, N)
+        rec(f"gemm+bias+res {tag} M{M} N{N} K{K}", timeit(lambda: ops.gemm(a, w, o, bias=bias, res=resid)), flops=2.0 * M * N * K)
+    for (M, C, tag) in [(B * 4096, 320, "64^2"), (B * 1024, 640, "32^2")]:
+        a, w, o = rnd(M, C), rnd(8 * C, C), ops.empty((M, 4 * C))
+        bias = torch.randn(8 * C, device="cuda")
+        rec(f"gemm+geglu {tag} M{M} N{8 * C} K{C}", timeit(lambda: ops.gemm(a, w, o, bias=bias, geglu=True)), flops=2.0 * M * 8 * C * C)
+
 for (H, Cin, Cout, tag) in [(64, 320, 320, "64^2 320"), (32, 640, 640, "32^2 640"), (16, 1280, 1280, "16^2 1280"),
                             (8, 2560, 1280, "8^2 2560->1280"), (64, 960, 320, "64^2 960->320"), (32, 1920, 640, "32^2 1920->640")]:
     x, w, o = rnd(B, H, H, Cin), rnd(Cout, 9 * Cin), ops.empty((B, H, H, Cout))

@@ -12,21 +12,15 @@
 // the concatenation (reference attention.py:307).
 //
 // Roofline: MFMA-bound; algorithmic flops = 4 * nq * (n0+n1) * d per (b, h).
-#include "common.h"
+#include "attn_core.h"
+#include <cstdlib>
+
+using namespace idfattn;
 
 namespace {
 
 constexpr int KVT = 64;            // kv rows per tile
 constexpr int VSTR = 72;           // V^T LDS row stride in elements (144 B = 9 x 16-B slots: conflict-free b128 reads)
-
-struct AttnParams {
-  const unsigned short* q; int ldq; long long sQ; int nq;
-  const unsigned short* k[2]; int ldk[2]; long long sK[2];
-  const unsigned short* vt[2]; int ldv[2]; long long sV[2]; int n[2];
-  unsigned short* out; int ldo; long long sO;
-  int H, d;
-  float scale_log2;   // d^-0.5 * log2(e)
-};
 
 // NKS = ceil(d/16) K-steps of the QK^T contraction, NMT = ceil(d/32) 32-row tiles of O^T.
 // MFMASUM: d < 32*NMT, i.e. the O^T tile has spare rows -> row d of the V^T image is set to ONES so the softmax
@@ -300,6 +294,13 @@ int launch_attn(const AttnParams& p, int B, hipStream_t s) {
 
 }  // namespace
 
+int g_attn2_mode = -2;
+int idf_attn2_mode() {
+  if (g_attn2_mode == -2) { const char* e = getenv("IDF_ATTN2"); g_attn2_mode = e ? atoi(e) : IDF_ATTN2_DEFAULT; }
+  return g_attn2_mode;
+}
+int idf_attn2_set_mode(int v) { const int prev = idf_attn2_mode(); g_attn2_mode = v; return prev; }
+
 extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
   if (!a || !a->q || !a->k0 || !a->vt0 || !a->out) return IDF_E_ARG;
   if (a->B <= 0 || a->H <= 0 || a->d <= 0 || (a->d % 8) || a->d > 160 || a->nq <= 0 || a->n0 <= 0 || a->n1 < 0) return IDF_E_ARG;
@@ -321,6 +322,10 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
   p.H = a->H; p.d = a->d;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
+  if (idf_attn2_mode() > 0) {
+    const int rc = idf_launch_attn2(p, a->B, a->dtype, s);
+    if (rc != IDF_ATTN2_UNSUPPORTED) return rc;
+  }
   if (a->dtype == IDF_BF16) return launch_attn<IDF_BF16>(p, a->B, s);
   if (a->dtype == IDF_F16) return launch_attn<IDF_F16>(p, a->B, s);
   return IDF_E_UNSUPPORTED;

@@ -1,0 +1,289 @@
+// attention2.hip -- attention forward, variant 2 (gfx950): 64 queries per wave, LDS-DMA staged K / V^T tiles.
+//
+// Why (measured, profiles/r01_shape_profile_B64.log): the 64x64-latent self / gated-self attention (d = 40, 4096-4280
+// keys) is 29 % of the UNet forward and attention.hip runs it at ~590 TFLOP/s.  There every wave owns 32 queries, so
+// each 64-key tile costs 14 ds_read_b128 per 14 MFMAs per wave plus a register round trip (global -> VGPR -> ds_write)
+// of the tile: with 5 workgroups per CU the LDS pipe is ~80 % busy.
+// This variant:
+//   * a wave owns TWO groups of 32 queries and every K / V^T fragment read from LDS feeds two MFMAs
+//     (14 reads per 28 MFMAs); a workgroup of 4 waves covers 256 queries, halving tile staging per flop as well;
+//   * the tiles are staged by LDS-DMA (global_load_lds_dwordx4), no staging registers, no ds_write:
+//       K   tile: 64 rows x d elements, linear rows of d*2 bytes -- conflict-free for ds_read_b128 because d/8 is ODD
+//                 (the kernel is instantiated for d = 8*(2*NKS-1): 24, 40, 56 -- d = 40 is the SD-1.5 64x64 level);
+//       V^T tile: d rows x 64 keys, 128-B rows, 16-B slot ^= (row >> 1) & 7 applied on the global source address;
+//   * the V^T image is in NATURAL key order, and so is the packed P fragment: the K fragment rows are read in a permuted
+//     order (the two middle 4-row blocks of every 16 keys exchanged) so that the S^T registers of a lane-half come out as
+//     8 consecutive keys per 16-key step -- no lane exchange, no permuted V^T image;
+//   * softmax denominator from an all-ones row d of the V^T image (d < 32*NMT always holds for these d);
+//   * the O rescale is skipped when no lane of the wave raised its running max (alpha == 1 exactly).
+// Same algorithm / numerics contract as attention.hip (online softmax in fp32, P rounded to 16 bit before P.V).
+// Requirements checked by idf_launch_attn2: d as above, n0 % 8 == 0, n1 % 8 == 0 (a partially valid 16-B V^T chunk cannot
+// be masked in flight; fully invalid chunks are redirected to a page of zeros).
+#include "attn_core.h"
+
+using namespace idfattn;
+
+namespace {
+
+__device__ __attribute__((aligned(128))) unsigned short idf_attn_zero_page[64];
+
+constexpr int KVT = 64;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int DT, int NKS, int NMT>
+__global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
+  constexpr int DCH = 2 * NKS - 1;                 // 16-B chunks per K row
+  constexpr int D = 8 * DCH;                       // head dim
+  constexpr int KSZ = KVT * D;                     // K stage (elements)
+  constexpr int VROWS = NMT * 32;
+  constexpr int VSZ = VROWS * KVT;                 // V^T stage (elements), 128-B rows
+  constexpr int STG = KSZ + VSZ;
+  constexpr int K_INST = DCH;                      // LDS-DMA instructions per K tile (64 chunks each)
+  constexpr int V_INST = D / 8;                    // per V^T tile (8 rows each)
+  constexpr int K_PER_WAVE = (K_INST + 3) / 4, V_PER_WAVE = (V_INST + 3) / 4;
+  static_assert(D < 32 * NMT, "needs a spare O^T row for the softmax denominator");
+  // The K fragment of the last K-step reads 8 elements past a row (zero Q columns multiply them): for the last row of
+  // the tile that is the first V^T row of the same stage -- always finite data.
+  __shared__ __attribute__((aligned(128))) unsigned short smem[2 * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+
+  // zero both stages once (pad rows of V^T must be finite zeros), then the ones row
+  for (int i = tid; i < STG; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+  __syncthreads();
+  {
+    const unsigned short one = Elem<DT>::from_f32(1.0f);
+    for (int i = tid; i < 2 * KVT; i += 256) smem[(i / KVT) * STG + KSZ + D * KVT + (i % KVT)] = one;
+  }
+
+  // ---- Q fragments (B operand) of the two query groups: lane holds q = l31, e = 16*ks + 8*hi .. +7
+  u32x4 qf[2][NKS];
+  int qrow[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    qrow[g] = blockIdx.x * 256 + wave * 64 + g * 32 + l31;
+    const int qr = min(qrow[g], p.nq - 1);
+    const unsigned short* qp = p.q + (size_t)b * p.sQ + (size_t)qr * p.ldq + h * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int e0 = ks * 16 + hi * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (e0 < D) v = *reinterpret_cast<const u32x4*>(qp + e0);
+      qf[g][ks] = v;
+    }
+  }
+
+  const int T0 = (p.n[0] + KVT - 1) / KVT;
+  const int T1 = (p.n[1] + KVT - 1) / KVT;
+  const int T = T0 + T1;
+
+  // ---- DMA roles.  K: instruction i (= wave + 4j) moves linear chunks 64 i .. 64 i + 63 of the tile: chunk g -> row g / DCH,
+  // column chunk g % DCH.  V^T: instruction i moves rows 8 i .. 8 i + 7: lane -> row 8 i + (lane >> 3), slot lane & 7.
+  int k_row[K_PER_WAVE], k_col[K_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < K_PER_WAVE; ++j) {
+    const int g = (wave + 4 * j) * 64 + lane;
+    k_row[j] = g / DCH;
+    k_col[j] = (g - k_row[j] * DCH) * 8;
+  }
+  int v_row[V_PER_WAVE], v_chunk[V_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < V_PER_WAVE; ++j) {
+    const int row = (wave + 4 * j) * 8 + (lane >> 3);
+    v_row[j] = row;
+    v_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);      // global 8-key chunk that lands in LDS slot lane & 7
+  }
+
+  auto issue_dma = [&](int t, int stage) {
+    const int seg = (t < T0) ? 0 : 1;
+    const int kv0 = (seg ? (t - T0) : t) * KVT;
+    const int n = p.n[seg];
+    const int ldk = p.ldk[seg], ldv = p.ldv[seg];
+    const unsigned short* kb = p.k[seg] + (size_t)b * p.sK[seg] + h * D;
+    const unsigned short* vb = p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * D) * ldv + kv0;
+    unsigned short* Ks = smem + stage * STG;
+    unsigned short* Vs = Ks + KSZ;
+#pragma unroll
+    for (int j = 0; j < K_PER_WAVE; ++j) {
+      if (wave + 4 * j < K_INST) {
+        const int kr = min(kv0 + k_row[j], n - 1);                     // tail rows: clamped, their scores are masked
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb + (size_t)kr * ldk + k_col[j]),
+                                         (lptr_t)(Ks + (wave + 4 * j) * 512), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V_PER_WAVE; ++j) {
+      if (wave + 4 * j < V_INST) {
+        const bool valid = (kv0 + v_chunk[j] * 8) < n;                 // n % 8 == 0: a chunk is all valid or all invalid
+        const unsigned short* src = valid ? vb + (size_t)v_row[j] * ldv + v_chunk[j] * 8 : idf_attn_zero_page + (lane & 7) * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + (wave + 4 * j) * 512), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o[2][NMT];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[g][mt][r] = 0.0f;
+  float m_run[2] = {-INFINITY, -INFINITY};
+  const float c = p.scale_log2;
+  const int v_sw = (l31 >> 1) & 7;                  // V^T fragment rows are mt*32 + l31
+  // K fragment row permutation: MFMA row i = 16u + 8a + 4h + j of a 32-key half carries key 16u + 8h + 4a + j (bits a and h
+  // swapped, i.e. the two middle 4-row blocks of every 16 exchanged).  S^T register r of lane-half `hi` sits in MFMA row
+  // (r&3) + 8*(r>>2) + 4*hi, so it then holds key 16*(r>>3) + 8*hi + (r&7): the 8 registers of one 16-key step are 8
+  // CONSECUTIVE keys in register order -- exactly the k order of the P.V operands, no lane exchange needed.
+  const int kperm = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+  __syncthreads();                                  // zero fill + ones rows complete before the first DMA lands on them
+  issue_dma(0, 0);
+  for (int t = 0; t < T; ++t) {
+    // tile t landed (every wave waits for ITS OWN DMA, then the barrier publishes all of them) and every wave is done
+    // with tile t-1, whose stage the next DMA overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < T) issue_dma(t + 1, (t + 1) & 1);
+    const unsigned short* Kc = smem + (t & 1) * STG;
+    const unsigned short* Vc = Kc + KSZ;
+    const int seg = (t < T0) ? 0 : 1;
+    const int kv0 = (seg ? (t - T0) : t) * KVT;
+    const int nvalid = p.n[seg] - kv0;              // >= 1
+
+    // ---- S^T = K Q^T for both query groups; every K fragment feeds two MFMAs
+    f32x16 s[2][2];                                 // [kv half][query group]
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const unsigned short* kf = Kc + (st * 32 + kperm) * D + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(kf + ks * 16);
+        if (ks == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[st][0] = Elem<DT>::mfma32(a, qf[0][0], zero);
+          s[st][1] = Elem<DT>::mfma32(a, qf[1][0], zero);
+        } else {
+          s[st][0] = Elem<DT>::mfma32(a, qf[0][ks], s[st][0]);
+          s[st][1] = Elem<DT>::mfma32(a, qf[1][ks], s[st][1]);
+        }
+      }
+    }
+    // ---- online softmax per group.  s[st][g][r]: key = kv0 + st*32 + 16*(r>>3) + 8*hi + (r&7), query = l31 of group g
+    float alpha[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (nvalid < KVT) {
+        int nv = nvalid;
+        asm volatile("" : "+s"(nv));                  // keep the 32 compares inside the (rare) tail branch
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = st * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+            s[st][g][r] = (kv >= nv) ? -INFINITY : s[st][g][r];
+          }
+      }
+      float mx = s[0][g][0];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][g][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[g], mx * c);                    // c > 0
+      alpha[g] = __builtin_amdgcn_exp2f(m_run[g] - m_new);            // first tile: exp2(-inf) = 0
+      m_run[g] = m_new;
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[st][g][r] = __builtin_amdgcn_exp2f(fmaf(s[st][g][r], c, -m_new));
+    }
+    // rescale O only when some lane's running max moved (alpha == 1 exactly otherwise) -- wave-uniform branch
+    if (__builtin_amdgcn_ballot_w64((alpha[0] != 1.0f) | (alpha[1] != 1.0f)) != 0) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[g][mt][r] *= alpha[g];
+    }
+
+    // ---- O^T += V^T P^T.  K-step (st, k2) = keys st*32 + 16*k2 .. +15; lane-half `hi` supplies keys 8*hi .. 8*hi+7 of the
+    // step from its registers 8*k2 .. 8*k2+7 (see kperm), the V^T fragment is a plain 16-B read of the same 8 keys.
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        u32x4 pf[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) pf[g][w] = pack2<DT>(s[st][g][8 * k2 + 2 * w], s[st][g][8 * k2 + 2 * w + 1]);
+        const int chunk = st * 4 + k2 * 2 + hi;            // 8-key chunk of the tile
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(Vc + (mt * 32 + l31) * KVT + ((chunk ^ v_sw) * 8));
+          o[0][mt] = Elem<DT>::mfma32(a, pf[0], o[0][mt]);
+          o[1][mt] = Elem<DT>::mfma32(a, pf[1], o[1][mt]);
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store.  o[g][mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31 of group g.
+  // row e = D of O^T holds l: tile D/32, register 4*((D%32)/8) of the hi = 0 lanes
+  constexpr int sel = (D & 31) >> 3;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float lv = o[g][NMT - 1][4 * sel];
+    const float l_tot = __shfl(lv, l31, 64);               // broadcast from the hi = 0 lane of this query
+    const float inv = 1.0f / l_tot;
+    if (qrow[g] < p.nq) {
+      unsigned short* op = p.out + (size_t)b * p.sO + (size_t)qrow[g] * p.ldo + h * D;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int e = mt * 32 + 8 * qd + 4 * hi;
+          if (e < D) {
+            u32x2 pk = {pack2<DT>(o[g][mt][4 * qd] * inv, o[g][mt][4 * qd + 1] * inv),
+                        pack2<DT>(o[g][mt][4 * qd + 2] * inv, o[g][mt][4 * qd + 3] * inv)};
+            *reinterpret_cast<u32x2*>(op + e) = pk;
+          }
+        }
+    }
+  }
+}
+
+template <int DT>
+int launch_attn2(const AttnParams& p, int B, hipStream_t s) {
+  dim3 grid((p.nq + 255) / 256, p.H, B), block(256);
+#define IDF_ATTN2_CASE(KS, MT) \
+  if (p.d == 8 * (2 * KS - 1)) { hipLaunchKernelGGL((attn2_kernel<DT, KS, MT>), grid, block, 0, s, p); return idf_launch_status(); }
+  IDF_ATTN2_CASE(2, 1)    // d = 24
+  IDF_ATTN2_CASE(3, 2)    // d = 40
+  IDF_ATTN2_CASE(4, 2)    // d = 56
+#undef IDF_ATTN2_CASE
+  return IDF_ATTN2_UNSUPPORTED;
+}
+
+}  // namespace
+
+long long idf_stat_attn2_launches = 0;
+
+int idf_launch_attn2(const AttnParams& p, int B, int dtype, hipStream_t s) {
+  if (p.d != 24 && p.d != 40 && p.d != 56) return IDF_ATTN2_UNSUPPORTED;
+  if ((p.n[0] % 8) || (p.n[1] % 8)) return IDF_ATTN2_UNSUPPORTED;
+  if ((p.ldk[0] % 8) || (p.ldv[0] % 8) || (p.n[1] > 0 && ((p.ldk[1] % 8) || (p.ldv[1] % 8)))) return IDF_ATTN2_UNSUPPORTED;
+  if (!aligned16(p.k[0]) || !aligned16(p.vt[0]) || !aligned16(p.k[1]) || !aligned16(p.vt[1])) return IDF_ATTN2_UNSUPPORTED;
+  if ((p.sK[0] % 8) || (p.sV[0] % 8) || (p.sK[1] % 8) || (p.sV[1] % 8)) return IDF_ATTN2_UNSUPPORTED;
+  int rc = IDF_ATTN2_UNSUPPORTED;
+  if (dtype == IDF_BF16) rc = launch_attn2<IDF_BF16>(p, B, s);
+  else if (dtype == IDF_F16) rc = launch_attn2<IDF_F16>(p, B, s);
+  if (rc != IDF_ATTN2_UNSUPPORTED) ++idf_stat_attn2_launches;
+  return rc;
+}

@@ -1,0 +1,26 @@
+// attn_core.h -- parameter block shared by the two attention translation units (attention.hip, attention2.hip).
+#pragma once
+#include "common.h"
+
+namespace idfattn {
+
+struct AttnParams {
+  const unsigned short* q; int ldq; long long sQ; int nq;
+  const unsigned short* k[2]; int ldk[2]; long long sK[2];
+  const unsigned short* vt[2]; int ldv[2]; long long sV[2]; int n[2];
+  unsigned short* out; int ldo; long long sO;
+  int H, d;
+  float scale_log2;   // d^-0.5 * log2(e)
+};
+
+}  // namespace idfattn
+
+// 64-queries-per-wave LDS-DMA kernel (attention2.hip); IDF_ATTN2_UNSUPPORTED when the shape does not qualify.
+#define IDF_ATTN2_UNSUPPORTED (-100)
+#ifndef IDF_ATTN2_DEFAULT
+#define IDF_ATTN2_DEFAULT 0
+#endif
+extern long long idf_stat_attn2_launches;
+int idf_attn2_mode();
+int idf_attn2_set_mode(int v);
+int idf_launch_attn2(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);

@@ -5,8 +5,8 @@ cd "$(dirname "$0")"
 OUT=../libidf_gfx950.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 OBJS=""
-for f in gemm_conv gemm_big attention norms scaleu misc convnext; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_core.h -nt build/$f.o ] || [ ../../include/idf.h -nt build/$f.o ]; then
+for f in gemm_conv gemm_big attention attention2 norms scaleu misc convnext; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_core.h -nt build/$f.o ] || [ attn_core.h -nt build/$f.o ] || [ ../../include/idf.h -nt build/$f.o ]; then
     mkdir -p build
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o build/$f.o &
   fi

@@ -9,6 +9,7 @@
 //
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops = 2*M*N*K.
 #include "gemm_core.h"
+#include "attn_core.h"
 #include <cstdlib>
 
 using namespace idfcore;
@@ -594,11 +595,16 @@ extern "C" int idf_set_tuning(int knob, int value) {
     g_big_mode = value;
     return prev;
   }
+  if (knob == IDF_TUNE_ATTN2) {
+    if (value < 0 || value > 1) return IDF_E_ARG;
+    return idf_attn2_set_mode(value);
+  }
   return IDF_E_ARG;
 }
 
 extern "C" long long idf_get_stat(int stat) {
   if (stat == IDF_STAT_GEMM_BIG_LAUNCHES) return idf_stat_big_launches;
+  if (stat == IDF_STAT_ATTN2_LAUNCHES) return idf_stat_attn2_launches;
   return -1;
 }
 

@@ -468,3 +468,77 @@ def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
     torch.cuda.synchronize()
     assert big() == 1
     assert relmax(out, want) < BF16_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention variant 2 (attention2.hip: 64 queries per wave, LDS-DMA staging), forced through idf_set_tuning
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def attn2():
+    from instancediffusion_amd import _lib
+    lib = _lib.load()
+    prev = lib.idf_set_tuning(1, 1)
+    start = lib.idf_get_stat(1)
+    yield lambda: lib.idf_get_stat(1) - start
+    lib.idf_set_tuning(1, prev)
+
+
+@pytest.mark.parametrize("B,H,d,Nq,n0,n1", [
+    (1, 8, 40, 256, 256, 0), (2, 8, 40, 256, 256, 184), (1, 8, 40, 4096, 4096, 184), (2, 8, 40, 200, 72, 0),
+    (1, 8, 40, 300, 304, 184), (1, 3, 24, 100, 128, 8), (2, 4, 56, 513, 520, 0), (1, 8, 40, 1000, 1000, 40)])
+def test_attention_v2(ops, ref, attn2, B, H, d, Nq, n0, n1):
+    C = H * d
+    q, k0, v0 = to16(gen((B, Nq, C), 40)), to16(gen((B, n0, C), 41)), to16(gen((B, n0, C), 42))
+    ld0 = (n0 + 63) // 64 * 64
+    vt0 = torch.full((B, C, ld0), float("nan"), dtype=torch.bfloat16)        # pad must never reach the output
+    vt0[:, :, :n0] = v0.transpose(1, 2)
+    kw = {}
+    rkw = {}
+    if n1:
+        k1, v1 = to16(gen((B, n1, C), 43)), to16(gen((B, n1, C), 44))
+        vt1 = torch.full((B, C, 192), float("nan"), dtype=torch.bfloat16)
+        vt1[:, :, :n1] = v1.transpose(1, 2)
+        kw = dict(k1=dev(k1), vt1=dev(vt1), n1=n1)
+        rkw = dict(k1=k1.float(), vt1=torch.nan_to_num(vt1.float()), n1=n1)
+    want = ref.attention(q.float(), k0.float(), torch.nan_to_num(vt0.float()), n0, torch.empty(B, Nq, C), H, **rkw)
+    out = ops.attention(dev(q), dev(k0), dev(vt0), n0, ops.empty((B, Nq, C)), H, **kw)
+    torch.cuda.synchronize()
+    assert attn2() == 1
+    assert torch.isfinite(out.float()).all()
+    assert relmax(out, want) < 2 * BF16_TOL
+
+
+def test_attention_v2_forced_rescale_and_strided_views(ops, ref, attn2):
+    """Late spike (rescale branch after many alpha == 1 tiles) on q/k column slices of a fused projection buffer."""
+    B, H, d, N = 2, 8, 40, 640
+    C = H * d
+    qk = gen((B, N, 2 * C), 45)
+    v = to16(gen((B, N, C), 47))
+    qk[:, 500, C:] = qk[:, 7, :C] * 4.0             # key 500 (8th tile) gets a huge score for query 7
+    qk[:, 3, C:] = qk[:, 300, :C] * 4.0             # and query 300 peaks in the FIRST tile (alpha stays 1 afterwards)
+    qk = to16(qk)
+    vt = v.transpose(1, 2).contiguous()
+    want = ref.attention(qk[:, :, :C].float(), qk[:, :, C:].float(), vt.float(), N, torch.empty(B, N, C), H)
+    dqk = dev(qk)
+    out = ops.attention(dqk[:, :, :C], dqk[:, :, C:], dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    assert attn2() == 1
+    assert relmax(out, want) < 2 * BF16_TOL
+
+
+def test_attention_v2_matches_v1(ops, attn2):
+    """Same inputs through both kernels: identical algorithm, only the fp32 summation order of P.V differs."""
+    from instancediffusion_amd import _lib
+    B, H, d, N = 1, 8, 40, 1024
+    C = H * d
+    q, k, v = to16(gen((B, N, C), 50)), to16(gen((B, N, C), 51)), to16(gen((B, N, C), 52))
+    vt = v.transpose(1, 2).contiguous()
+    o2 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    assert attn2() == 1
+    _lib.load().idf_set_tuning(1, 0)
+    o1 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    _lib.load().idf_set_tuning(1, 1)
+    assert attn2() == 1
+    assert relmax(o2, o1) < BF16_TOL

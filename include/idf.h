@@ -47,7 +47,7 @@ const char* idf_build_info(void);
  *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256}-tile GEMM/conv kernel, 1 = automatic
  *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default.
  *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel, 1 = use the 64-queries-per-wave LDS-DMA
- *   kernel when the shape qualifies (d in {24,40,56}, n0 % 8 == n1 % 8 == 0).  Initial value: env IDF_ATTN2 or default. */
+ *   kernel, 2 = its software-pipelined form (softmax of one query group beside the MFMAs of the other), when the shape qualifies (d in {24,40,56}, n0 % 8 == n1 % 8 == 0).  Initial value: env IDF_ATTN2 or default. */
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
@@ -139,7 +139,7 @@ int idf_dwconv7x7(const void* x, const float* w_tap_major, const float* bias, vo
 /* ---- ScaleU (openaimodel.py:519-539 + Fourier_filter :25-48) ---------------------------------------------
  * out[b,p,0:Ch] = h * hscale[c];  out[b,p,Ch:Ch+Cs] = skip + sm1[0] * lowfreq4(skip)   (exact 4-bin identity)
  * hscale = tanh(scaleu_b)+1 (f32 [Ch]); sm1 = tanh(scaleu_s) (f32 scalar on device).
- * ws: f32 workspace of B*Cs*8 floats.                                                                        */
+ * ws: f32 workspace of B*Cs*64 floats (8 row slices of partial plane sums); hscale 16-B aligned.            */
 int idf_scaleu_concat(const void* h, const void* skip, void* out, const float* hscale, const float* sm1,
                       float* ws, int B, int H, int W, int Ch, int Cs, int dtype, void* stream);
 

@@ -259,11 +259,309 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Variant 3: the same data layout, software-pipelined INSIDE the wave.  PMC on variant 2 (profiles/r01_pmc_attention.log):
+// the MFMA pipe is busy 41 % and the wave spends its time in VALU (softmax) and MFMA phases one after the other -- with 2
+// waves per SIMD that start every tile together behind the same kind of barrier, the phases of the two waves coincide
+// instead of interleaving.  Here each half-iteration ("slot") pairs the softmax of one query group (VALU: ~100
+// instructions, 33 of them v_exp_f32) with MFMAs that do not depend on it:
+//   slot A(t):  softmax(a, t)   ||   P.V(b, t-1)  (8 MFMA)  +  K.Q^T(b, t)    (6 MFMA)
+//   slot B(t):  softmax(b, t)   ||   P.V(a, t)    (8 MFMA)  +  K.Q^T(a, t+1)  (6 MFMA)
+// so both pipes have ~450 cycles of independent work per slot and all dependencies run slot -> next slot.
+// A 3-stage LDS ring (tile t-1 is still read in slot A(t) while tile t+1 lands); one barrier per tile, at the A|B boundary.
+// The tail tile needs NO masking arithmetic: its K rows beyond n are clamped duplicates of the last valid key (a valid
+// score, so the running max is unaffected), its V^T columns beyond n come from the page of zeros, and the all-ones row
+// that produces the softmax denominator is re-staged per tile from a ones / zeros page pair with the same validity rule.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(128))) unsigned short idf_attn_ones_page[2][64] = {
+    {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80,
+     0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80,
+     0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80,
+     0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80},
+    {0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00,
+     0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00,
+     0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00,
+     0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00, 0x3c00}};
+
+template <int I> struct AIC { static constexpr int value = I; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for_a(F&& f) {
+  if constexpr (I < N) { f(AIC<I>{}); static_for_a<I + 1, N>(f); }
+}
+
+template <int DT, int NKS, int NMT>
+__global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
+  constexpr int DCH = 2 * NKS - 1;
+  constexpr int D = 8 * DCH;
+  constexpr int KSZ = KVT * D;
+  constexpr int VROWS = NMT * 32;
+  constexpr int VSZ = VROWS * KVT;
+  constexpr int STG = KSZ + VSZ;
+  constexpr int NSTG = 3;
+  constexpr int K_INST = DCH;
+  constexpr int V_INST = D / 8 + 1;                // + the 8-row group that starts with the ones row (row D)
+  constexpr int K_PER_WAVE = (K_INST + 3) / 4, V_PER_WAVE = (V_INST + 3) / 4;
+  static_assert(D + 8 <= VROWS, "ones-row group must fit the V^T image");
+  __shared__ __attribute__((aligned(128))) unsigned short smem[NSTG * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+
+  for (int i = tid; i < NSTG * STG / 2; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+  u32x4 qf[2][NKS];
+  int qrow[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    qrow[g] = blockIdx.x * 256 + wave * 64 + g * 32 + l31;
+    const int qr = min(qrow[g], p.nq - 1);
+    const unsigned short* qp = p.q + (size_t)b * p.sQ + (size_t)qr * p.ldq + h * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int e0 = ks * 16 + hi * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (e0 < D) v = *reinterpret_cast<const u32x4*>(qp + e0);
+      qf[g][ks] = v;
+    }
+  }
+
+  const int T0 = (p.n[0] + KVT - 1) / KVT;
+  const int T1 = (p.n[1] + KVT - 1) / KVT;
+  const int T = T0 + T1;
+
+  int k_row[K_PER_WAVE], k_col[K_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < K_PER_WAVE; ++j) {
+    const int g = (wave + 4 * j) * 64 + lane;
+    k_row[j] = g / DCH;
+    k_col[j] = (g - k_row[j] * DCH) * 8;
+  }
+  int v_row[V_PER_WAVE], v_chunk[V_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < V_PER_WAVE; ++j) {
+    const int row = (wave + 4 * j) * 8 + (lane >> 3);
+    v_row[j] = row;
+    v_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);
+  }
+  const unsigned short* ones = idf_attn_ones_page[DT == IDF_BF16 ? 0 : 1];
+
+  auto issue_dma = [&](int t, int stage) {
+    const int seg = (t < T0) ? 0 : 1;
+    const int kv0 = (seg ? (t - T0) : t) * KVT;
+    const int n = p.n[seg];
+    const int ldk = p.ldk[seg], ldv = p.ldv[seg];
+    const unsigned short* kb = p.k[seg] + (size_t)b * p.sK[seg] + h * D;
+    const unsigned short* vb = p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * D) * ldv + kv0;
+    unsigned short* Ks = smem + stage * STG;
+    unsigned short* Vs = Ks + KSZ;
+#pragma unroll
+    for (int j = 0; j < K_PER_WAVE; ++j) {
+      if (wave + 4 * j < K_INST) {
+        const int kr = min(kv0 + k_row[j], n - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb + (size_t)kr * ldk + k_col[j]),
+                                         (lptr_t)(Ks + (wave + 4 * j) * 512), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V_PER_WAVE; ++j) {
+      if (wave + 4 * j < V_INST) {
+        const bool valid = (kv0 + v_chunk[j] * 8) < n;
+        const unsigned short* src = idf_attn_zero_page + (lane & 7) * 8;
+        if (valid) src = (v_row[j] < D) ? vb + (size_t)v_row[j] * ldv + v_chunk[j] * 8
+                                        : ((v_row[j] == D) ? ones + (lane & 7) * 8 : src);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + (wave + 4 * j) * 512), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o[2][NMT], s[2][2];                        // s[group][kv half]
+  u32x4 pk[2][2][2];                                // packed P: [group][kv half][16-key step]
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[g][mt][r] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) pk[g][st][k2] = u32x4{0u, 0u, 0u, 0u};
+  }
+  float m_run[2] = {-INFINITY, -INFINITY};
+  const float c = p.scale_log2;
+  const int v_sw = (l31 >> 1) & 7;
+  const int kperm = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int koff = kperm * D + hi * 8;                        // K fragment element offset inside a 32-key half
+  const int voff = l31 * KVT;                                 // V^T fragment row offset
+
+  // The slot's MFMA list for group mg: i < 4*NMT: P.V step (st, k2, mt) out of the V^T image Vp; then K.Q^T step (st, ks)
+  // out of the K image Kq.  frag_read / mfma_do are separate so the LDS reads run two steps ahead of their MFMAs.
+  auto frag_read = [&](auto II, const unsigned short* Kq, const unsigned short* Vp) -> u32x4 {
+    constexpr int i = decltype(II)::value;
+    if constexpr (i < 4 * NMT) {
+      constexpr int st = i / (2 * NMT), k2 = (i / NMT) & 1, mt = i % NMT;
+      const int chunk = st * 4 + k2 * 2 + hi;
+      return *reinterpret_cast<const u32x4*>(Vp + mt * 32 * KVT + voff + ((chunk ^ v_sw) * 8));
+    } else {
+      constexpr int j = i - 4 * NMT, st = j / NKS, ks = j % NKS;
+      return *reinterpret_cast<const u32x4*>(Kq + st * 32 * D + koff + ks * 16);
+    }
+  };
+  auto mfma_do = [&](auto II, auto MG, const u32x4 a) {
+    constexpr int i = decltype(II)::value, mg = decltype(MG)::value;
+    if constexpr (i < 4 * NMT) {
+      constexpr int st = i / (2 * NMT), k2 = (i / NMT) & 1, mt = i % NMT;
+      o[mg][mt] = Elem<DT>::mfma32(a, pk[mg][st][k2], o[mg][mt]);
+    } else {
+      constexpr int j = i - 4 * NMT, st = j / NKS, ks = j % NKS;
+      if constexpr (ks == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        s[mg][st] = Elem<DT>::mfma32(a, qf[mg][0], zero);
+      } else {
+        s[mg][st] = Elem<DT>::mfma32(a, qf[mg][ks], s[mg][st]);
+      }
+    }
+  };
+  constexpr int NM = 4 * NMT + 2 * NKS;              // MFMAs per slot (14 for d = 40)
+  constexpr int NM1 = 3;                             // of which issued beside the max chain
+
+  // slot: VALU softmax of group vg (scores s[vg] -> packed pk[vg], running max, O rescale) interleaved in PROGRAM ORDER
+  // with the NM independent MFMAs of group 1-vg.  sched_barrier(0) after every step pins "one MFMA + its share of the
+  // softmax" together (hipcc otherwise sinks the whole softmax next to its consumer in the NEXT slot).
+  auto slot = [&](auto VG, const unsigned short* Kq, const unsigned short* Vp) {
+    constexpr int vg = decltype(VG)::value, mg = 1 - vg;
+    u32x4 fr[3];
+    fr[0] = frag_read(AIC<0>{}, Kq, Vp);
+    fr[1] = frag_read(AIC<1>{}, Kq, Vp);
+    // ---- part 1: max chain beside the first MFMAs
+    fr[2] = frag_read(AIC<2>{}, Kq, Vp);
+    mfma_do(AIC<0>{}, AIC<mg>{}, fr[0]);
+    float mx0 = fmaxf(s[vg][0][0], s[vg][0][1]), mx1 = fmaxf(s[vg][1][0], s[vg][1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) { mx0 = fmaxf(fmaxf(mx0, s[vg][0][r]), s[vg][0][r + 1]); }
+    __builtin_amdgcn_sched_barrier(0);
+    fr[0] = frag_read(AIC<3>{}, Kq, Vp);
+    mfma_do(AIC<1>{}, AIC<mg>{}, fr[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) { mx1 = fmaxf(fmaxf(mx1, s[vg][1][r]), s[vg][1][r + 1]); }
+    float mx = fmaxf(mx0, mx1);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fr[1] = frag_read(AIC<4>{}, Kq, Vp);
+    mfma_do(AIC<2>{}, AIC<mg>{}, fr[2]);
+    const float m_new = fmaxf(m_run[vg], mx * c);
+    const float alpha = __builtin_amdgcn_exp2f(m_run[vg] - m_new);
+    m_run[vg] = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[vg][mt][r] *= alpha;
+    }
+    // ---- part 2: 32 x (fma, exp2) + 16 cvt_pk spread over the remaining MFMAs
+    constexpr int REST = NM - NM1;
+    constexpr int PER = (32 + REST - 1) / REST;        // scores handled after each MFMA
+    static_for_a<0, REST>([&](auto JJ) {
+      constexpr int j = decltype(JJ)::value, i = NM1 + j;
+      if constexpr (i + 2 < NM) fr[(i + 2) % 3] = frag_read(AIC<i + 2>{}, Kq, Vp);
+      mfma_do(AIC<i>{}, AIC<mg>{}, fr[i % 3]);
+#pragma unroll
+      for (int e = j * PER; e < (j + 1) * PER && e < 32; ++e) {
+        const int st = e >> 4, r = e & 15;
+        s[vg][st][r] = __builtin_amdgcn_exp2f(fmaf(s[vg][st][r], c, -m_new));
+        if ((e & 1) == 1) {
+          const int k2 = r >> 3, w = (r & 7) >> 1;
+          unsigned pw = pack2<DT>(s[vg][st][r - 1], s[vg][st][r]);
+          asm volatile("" : "+v"(pw));                // opaque use: keeps the softmax HERE (LLVM otherwise sinks it to its
+          pk[vg][st][k2][w] = pw;                     // consumer, the P.V MFMAs of the next slot)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  __syncthreads();                                  // zero fill complete
+  issue_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (T > 1) issue_dma(1, 1);
+  {                                                 // prologue: S_a of tile 0
+    const unsigned short* Kq = smem;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(Kq + st * 32 * D + koff + ks * 16);
+        if (ks == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[0][st] = Elem<DT>::mfma32(a, qf[0][0], zero);
+        } else {
+          s[0][st] = Elem<DT>::mfma32(a, qf[0][ks], s[0][st]);
+        }
+      }
+  }
+  int st_cur = 0, st_prev = 2, st_next = 1;         // ring stage of tile t, t-1, t+1
+  for (int t = 0; t < T; ++t) {
+    // slot A: softmax(a, t) || P.V(b, t-1) [stage of t-1; all zeros for t = 0] + K.Q^T(b, t)
+    slot(AIC<0>{}, smem + st_cur * STG, smem + st_prev * STG + KSZ);
+    // tile t+1 landed (own DMA, then the barrier publishes everyone's); every wave is past its last read of tile t-1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < T) issue_dma(t + 2, st_prev);
+    // slot B: softmax(b, t) || P.V(a, t) + K.Q^T(a, t+1)   (for t = T-1 the K.Q^T reads a stale stage; its result is unused)
+    slot(AIC<1>{}, smem + st_next * STG, smem + st_cur * STG + KSZ);
+    const int tmp = st_prev; st_prev = st_cur; st_cur = st_next; st_next = tmp;
+  }
+  // epilogue: P.V(b, T-1)
+  {
+    const unsigned short* Vp = smem + st_prev * STG + KSZ;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int chunk = st * 4 + k2 * 2 + hi;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(Vp + mt * 32 * KVT + voff + ((chunk ^ v_sw) * 8));
+          o[1][mt] = Elem<DT>::mfma32(a, pk[1][st][k2], o[1][mt]);
+        }
+      }
+  }
+
+  constexpr int sel = (D & 31) >> 3;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float lv = o[g][NMT - 1][4 * sel];
+    const float l_tot = __shfl(lv, l31, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow[g] < p.nq) {
+      unsigned short* op = p.out + (size_t)b * p.sO + (size_t)qrow[g] * p.ldo + h * D;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int e = mt * 32 + 8 * qd + 4 * hi;
+          if (e < D) {
+            u32x2 pkd = {pack2<DT>(o[g][mt][4 * qd] * inv, o[g][mt][4 * qd + 1] * inv),
+                         pack2<DT>(o[g][mt][4 * qd + 2] * inv, o[g][mt][4 * qd + 3] * inv)};
+            *reinterpret_cast<u32x2*>(op + e) = pkd;
+          }
+        }
+    }
+  }
+}
+
 template <int DT>
 int launch_attn2(const AttnParams& p, int B, hipStream_t s) {
   dim3 grid((p.nq + 255) / 256, p.H, B), block(256);
 #define IDF_ATTN2_CASE(KS, MT) \
-  if (p.d == 8 * (2 * KS - 1)) { hipLaunchKernelGGL((attn2_kernel<DT, KS, MT>), grid, block, 0, s, p); return idf_launch_status(); }
+  if (p.d == 8 * (2 * KS - 1)) { \
+    if (idf_attn2_mode() >= 2) hipLaunchKernelGGL((attn3_kernel<DT, KS, MT>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((attn2_kernel<DT, KS, MT>), grid, block, 0, s, p); \
+    return idf_launch_status(); }
   IDF_ATTN2_CASE(2, 1)    // d = 24
   IDF_ATTN2_CASE(3, 2)    // d = 40
   IDF_ATTN2_CASE(4, 2)    // d = 56

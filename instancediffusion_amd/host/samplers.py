@@ -220,6 +220,30 @@ class PLMSSamplerInst(_PLMSBase):
         x_units: Dict[tuple, torch.Tensor] = {}
         eps_units: Dict[tuple, list] = {}
         same_start = all(inp["x"] is input_all[0]["x"] or torch.equal(inp["x"], input_all[0]["x"]) for inp in input_all[1:])
+        # Exact hoist of the very first evaluation: every instance trajectory of image b still holds the SAME latent (the
+        # shared starting noise, inference.py:300-301) and the unconditional branch sees only (x, t, uc, null grounding),
+        # so it is identical for the N+1 instances of an image.  Evaluate all conditional rows of this rank's units plus
+        # ONE unconditional row per image up front, in full-width forwards, instead of one unconditional row per unit.
+        first_idx: Dict[tuple, int] = {}
+        first_unc: Dict[int, int] = {}
+        E_first = None
+        if guided and same_start and units and mis_step > 0 and not serial:
+            self._apply_alpha(alphas, 0)
+            imgs = sorted({b for (_, b) in units})
+            row_ids = [j * B + b for (j, b) in units] + [n_all * B + b for b in imgs]
+            row_img = [b for (_, b) in units] + imgs
+            first_idx = {u: k for k, u in enumerate(units)}
+            first_unc = {b: len(units) + k for k, b in enumerate(imgs)}
+            x0_all = input_all[0]["x"].to(dev, torch.float32)
+            width = 2 * self.max_units
+            parts = []
+            for k in range(0, len(row_ids), width):
+                r = torch.tensor(row_ids[k:k + width], device=dev, dtype=torch.long)
+                xx = x0_all[torch.tensor(row_img[k:k + width], device=dev, dtype=torch.long)]
+                tt = torch.full((xx.shape[0],), float(time_range[0]), device=dev, dtype=torch.float32)
+                slot = eng.gather_cond(bank, r)
+                parts.append(eng.forward_cond(xx, tt, slot, out=eng.buf("smp.eps_first", xx.shape, torch.float32)).clone())
+            E_first = torch.cat(parts, 0)
         for chunk in chunks:
             if not chunk:
                 continue
@@ -232,21 +256,10 @@ class PLMSSamplerInst(_PLMSBase):
                 index = total - i - 1
                 step_next = int(time_range[min(i + 1, len(time_range) - 1)])
                 e_first = None
-                if i == 0 and guided and same_start:
-                    # Exact hoist: at the very first evaluation every instance trajectory of image b still holds the
-                    # SAME latent (the shared starting noise, inference.py:300-301) and the unconditional branch sees
-                    # only (x, t, uc, null grounding) -> it is identical for the N+1 instances of an image: evaluate it
-                    # once per image instead of once per (instance, image) unit.
-                    imgs = sorted({b for (_, b) in chunk})
-                    pos = {b: k for k, b in enumerate(imgs)}
-                    r = [j * B + b for (j, b) in chunk] + [n_all * B + b for b in imgs]
-                    slot = eng.gather_cond(bank, torch.tensor(r, device=dev, dtype=torch.long))
-                    xu = torch.stack([input_all[0]["x"][b] for b in imgs]).to(dev, torch.float32)
-                    xx = torch.cat([x, xu], 0)
-                    tt = torch.full((xx.shape[0],), float(step), device=dev, dtype=torch.float32)
-                    e2 = eng.forward_cond(xx, tt, slot, out=eng.buf("smp.eps_first", xx.shape, torch.float32))
-                    e_uc = e2[n:][torch.tensor([pos[b] for (_, b) in chunk], device=dev)]
-                    e_first = ops.cfg_combine(e2[:n].contiguous(), e_uc.contiguous(), guidance_scale,
+                if i == 0 and E_first is not None:
+                    ic = torch.tensor([first_idx[u] for u in chunk], device=dev, dtype=torch.long)
+                    iu = torch.tensor([first_unc[b] for (_, b) in chunk], device=dev, dtype=torch.long)
+                    e_first = ops.cfg_combine(E_first[ic].contiguous(), E_first[iu].contiguous(), guidance_scale,
                                               ops.empty(x.shape, torch.float32))
                 if i == 0 or pair is None:
                     pair = eng.gather_cond(bank, rows(chunk))

@@ -212,7 +212,7 @@ class HipOps:
         B, H, W_, Ch = h.shape
         Cs = skip.shape[-1]
         assert h.is_contiguous() and skip.is_contiguous() and out.is_contiguous() and out.shape[-1] == Ch + Cs
-        ws = self._workspace("scaleu", B * Cs * 8)
+        ws = self._workspace("scaleu", B * Cs * 64)
         _lib.check(self.lib.idf_scaleu_concat(_p(h), _p(skip), _p(out), _p(hscale), _p(sm1), _p(ws), B, H, W_, Ch, Cs,
                                               self.dt, self._stream()), "idf_scaleu_concat")
         return out

@@ -259,7 +259,7 @@ def test_layernorm(ops, ref, M, C):
 
 
 @pytest.mark.parametrize("B,H,W,Ch,Cs", [(2, 8, 8, 1280, 1280), (1, 64, 64, 320, 320), (1, 16, 16, 1280, 640),
-                                         (2, 12, 12, 128, 64), (1, 24, 48, 64, 64)])
+                                         (2, 12, 12, 128, 64), (1, 24, 48, 64, 64), (3, 96, 96, 72, 40), (2, 32, 32, 640, 640)])
 def test_scaleu_concat(ops, B, H, W, Ch, Cs):
     from oracle import ref_cpu
     h, skip = to16(gen((B, H, W, Ch), 56)), to16(gen((B, H, W, Cs), 57) + 0.5)
@@ -473,11 +473,11 @@ def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
 # ---------------------------------------------------------------------------------------------------
 # attention variant 2 (attention2.hip: 64 queries per wave, LDS-DMA staging), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture()
-def attn2():
+@pytest.fixture(params=[1, 2], ids=["v2", "v3-pipelined"])
+def attn2(request):
     from instancediffusion_amd import _lib
     lib = _lib.load()
-    prev = lib.idf_set_tuning(1, 1)
+    prev = lib.idf_set_tuning(1, request.param)
     start = lib.idf_get_stat(1)
     yield lambda: lib.idf_get_stat(1) - start
     lib.idf_set_tuning(1, prev)
@@ -536,9 +536,9 @@ def test_attention_v2_matches_v1(ops, attn2):
     o2 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
     torch.cuda.synchronize()
     assert attn2() == 1
-    _lib.load().idf_set_tuning(1, 0)
+    mode = _lib.load().idf_set_tuning(1, 0)
     o1 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
     torch.cuda.synchronize()
-    _lib.load().idf_set_tuning(1, 1)
+    _lib.load().idf_set_tuning(1, mode)
     assert attn2() == 1
     assert relmax(o2, o1) < BF16_TOL

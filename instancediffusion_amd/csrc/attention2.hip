@@ -32,7 +32,18 @@ constexpr int KVT = 64;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int DT, int NKS, int NMT>
+// LAZY = true ("lazy rescaling"): the VALU work per score drops from {fma, exp2, 1/2 max, 1/2 cvt} to {exp2, 1/2 max, 1/2 cvt}:
+//   * Q is pre-multiplied by scale*log2(e) when it is loaded (rounded to 16 bit once -- the same thing torch's math SDPA
+//     does with q * sqrt(scale)), so the MFMA result is already the exponent;
+//   * the running reference value m of each query is SUBTRACTED BY THE MFMA ITSELF: the accumulator of K.Q^T is initialised
+//     with -m (16 registers per group holding -m) instead of 0;
+//   * m is not the exact running max but a LAGGING one: it is only raised (and O rescaled, the -m registers rewritten,
+//     the current tile re-based) when some score of the tile exceeds it by more than 2^LAZY_THR -- exact arithmetic either
+//     way (softmax is shift invariant; P <= 2^LAZY_THR keeps the same relative precision in bf16 / fp32).  The first tile
+//     always re-bases to its exact max.
+constexpr float LAZY_THR = 8.0f;
+
+template <int DT, int NKS, int NMT, bool LAZY>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
   constexpr int DCH = 2 * NKS - 1;                 // 16-B chunks per K row
   constexpr int D = 8 * DCH;                       // head dim
@@ -73,6 +84,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
       const int e0 = ks * 16 + hi * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (e0 < D) v = *reinterpret_cast<const u32x4*>(qp + e0);
+      if constexpr (LAZY) {
+        float f[8];
+        unpack8<DT>(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2;
+        v = pack8<DT>(f);
+      }
       qf[g][ks] = v;
     }
   }
@@ -132,7 +150,12 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[g][mt][r] = 0.0f;
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {LAZY ? 0.0f : -INFINITY, LAZY ? 0.0f : -INFINITY};
+  f32x16 cinit[2];                                  // LAZY: -m_lag of the group's query in every register (MFMA C operand)
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[g][r] = 0.0f;
   const float c = p.scale_log2;
   const int v_sw = (l31 >> 1) & 7;                  // V^T fragment rows are mt*32 + l31
   // K fragment row permutation: MFMA row i = 16u + 8a + 4h + j of a 32-key half carries key 16u + 8h + 4a + j (bits a and h
@@ -164,15 +187,72 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
       for (int ks = 0; ks < NKS; ++ks) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(kf + ks * 16);
         if (ks == 0) {
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          s[st][0] = Elem<DT>::mfma32(a, qf[0][0], zero);
-          s[st][1] = Elem<DT>::mfma32(a, qf[1][0], zero);
+          if constexpr (LAZY) {
+            s[st][0] = Elem<DT>::mfma32(a, qf[0][0], cinit[0]);
+            s[st][1] = Elem<DT>::mfma32(a, qf[1][0], cinit[1]);
+          } else {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            s[st][0] = Elem<DT>::mfma32(a, qf[0][0], zero);
+            s[st][1] = Elem<DT>::mfma32(a, qf[1][0], zero);
+          }
         } else {
           s[st][0] = Elem<DT>::mfma32(a, qf[0][ks], s[st][0]);
           s[st][1] = Elem<DT>::mfma32(a, qf[1][ks], s[st][1]);
         }
       }
     }
+    if constexpr (LAZY) {
+      // ---- lazy-rescaling softmax: s already is (score*scale*log2e - m_lag) of its query
+      float pm[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (nvalid < KVT) {
+          int nv = nvalid;
+          asm volatile("" : "+s"(nv));
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kv = st * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+              s[st][g][r] = (kv >= nv) ? -INFINITY : s[st][g][r];
+            }
+        }
+        float m0 = fmaxf(s[0][g][0], s[0][g][1]), m1 = fmaxf(s[1][g][0], s[1][g][1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+          m0 = fmaxf(fmaxf(m0, s[0][g][r]), s[0][g][r + 1]);
+          m1 = fmaxf(fmaxf(m1, s[1][g][r]), s[1][g][r + 1]);
+        }
+        pm[g] = fmaxf(m0, m1);
+      }
+      if (t == 0 || __builtin_amdgcn_ballot_w64((pm[0] > LAZY_THR) | (pm[1] > LAZY_THR)) != 0) {
+        // re-base (rare after the first tiles): exact max of the tile per query, shift the tile, rescale O (its row D is l)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(pm[g]), __float_as_uint(pm[g]), false, false);
+          const float mx = fmaxf(pm[g], __uint_as_float(hi ? sw[0] : sw[1]));
+          const float delta = (t == 0) ? mx : fmaxf(mx, 0.0f);
+          const float al = __builtin_amdgcn_exp2f(-delta);
+          m_run[g] += delta;                                  // m_run starts at 0 in this mode
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[st][g][r] -= delta;
+#pragma unroll
+          for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[g][mt][r] *= al;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cinit[g][r] = -m_run[g];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[st][g][r] = __builtin_amdgcn_exp2f(s[st][g][r]);
+    } else {
     // ---- online softmax per group.  s[st][g][r]: key = kv0 + st*32 + 16*(r>>3) + 8*hi + (r&7), query = l31 of group g
     float alpha[2];
 #pragma unroll
@@ -210,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[g][mt][r] *= alpha[g];
+    }
     }
 
     // ---- O^T += V^T P^T.  K-step (st, k2) = keys st*32 + 16*k2 .. +15; lane-half `hi` supplies keys 8*hi .. 8*hi+7 of the
@@ -288,7 +369,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for_a(F&
   if constexpr (I < N) { f(AIC<I>{}); static_for_a<I + 1, N>(f); }
 }
 
-template <int DT, int NKS, int NMT>
+template <int DT, int NKS, int NMT, bool LAZY>
 __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
   constexpr int DCH = 2 * NKS - 1;
   constexpr int D = 8 * DCH;
@@ -321,6 +402,13 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
       const int e0 = ks * 16 + hi * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (e0 < D) v = *reinterpret_cast<const u32x4*>(qp + e0);
+      if constexpr (LAZY) {
+        float f[8];
+        unpack8<DT>(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2;
+        v = pack8<DT>(f);
+      }
       qf[g][ks] = v;
     }
   }
@@ -387,7 +475,12 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) pk[g][st][k2] = u32x4{0u, 0u, 0u, 0u};
   }
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {LAZY ? 0.0f : -INFINITY, LAZY ? 0.0f : -INFINITY};
+  f32x16 cinit[2];                                  // LAZY: -m_lag of the group's query in every register (MFMA C operand)
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[g][r] = 0.0f;
   const float c = p.scale_log2;
   const int v_sw = (l31 >> 1) & 7;
   const int kperm = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
@@ -415,8 +508,12 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
     } else {
       constexpr int j = i - 4 * NMT, st = j / NKS, ks = j % NKS;
       if constexpr (ks == 0) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        s[mg][st] = Elem<DT>::mfma32(a, qf[mg][0], zero);
+        if constexpr (LAZY) {
+          s[mg][st] = Elem<DT>::mfma32(a, qf[mg][0], cinit[mg]);
+        } else {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[mg][st] = Elem<DT>::mfma32(a, qf[mg][0], zero);
+        }
       } else {
         s[mg][st] = Elem<DT>::mfma32(a, qf[mg][ks], s[mg][st]);
       }
@@ -428,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
   // slot: VALU softmax of group vg (scores s[vg] -> packed pk[vg], running max, O rescale) interleaved in PROGRAM ORDER
   // with the NM independent MFMAs of group 1-vg.  sched_barrier(0) after every step pins "one MFMA + its share of the
   // softmax" together (hipcc otherwise sinks the whole softmax next to its consumer in the NEXT slot).
-  auto slot = [&](auto VG, const unsigned short* Kq, const unsigned short* Vp) {
+  auto slot = [&](auto VG, const unsigned short* Kq, const unsigned short* Vp, const bool first) {
     constexpr int vg = decltype(VG)::value, mg = 1 - vg;
     u32x4 fr[3];
     fr[0] = frag_read(AIC<0>{}, Kq, Vp);
@@ -445,21 +542,44 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 2; r < 16; r += 2) { mx1 = fmaxf(fmaxf(mx1, s[vg][1][r]), s[vg][1][r + 1]); }
     float mx = fmaxf(mx0, mx1);
-    {
+    float m_new = 0.0f;
+    if constexpr (!LAZY) {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
     }
     __builtin_amdgcn_sched_barrier(0);
     fr[1] = frag_read(AIC<4>{}, Kq, Vp);
     mfma_do(AIC<2>{}, AIC<mg>{}, fr[2]);
-    const float m_new = fmaxf(m_run[vg], mx * c);
-    const float alpha = __builtin_amdgcn_exp2f(m_run[vg] - m_new);
-    m_run[vg] = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+    if constexpr (LAZY) {
+      // lazy rescaling (see attn2_kernel): s already is exponent - m_lag; re-base only on the first tile or when a score
+      // of this tile exceeds the lagging reference by more than 2^LAZY_THR
+      if (first || __builtin_amdgcn_ballot_w64(mx > LAZY_THR) != 0) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
+        const float delta = first ? mx : fmaxf(mx, 0.0f);
+        const float al = __builtin_amdgcn_exp2f(-delta);
+        m_run[vg] += delta;
 #pragma unroll
-      for (int mt = 0; mt < NMT; ++mt)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[vg][mt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) s[vg][st][r] -= delta;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[vg][mt][r] *= al;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[vg][r] = -m_run[vg];
+      }
+    } else {
+      m_new = fmaxf(m_run[vg], mx * c);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[vg] - m_new);
+      m_run[vg] = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[vg][mt][r] *= alpha;
+      }
     }
     // ---- part 2: 32 x (fma, exp2) + 16 cvt_pk spread over the remaining MFMAs
     constexpr int REST = NM - NM1;
@@ -471,7 +591,8 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
 #pragma unroll
       for (int e = j * PER; e < (j + 1) * PER && e < 32; ++e) {
         const int st = e >> 4, r = e & 15;
-        s[vg][st][r] = __builtin_amdgcn_exp2f(fmaf(s[vg][st][r], c, -m_new));
+        if constexpr (LAZY) s[vg][st][r] = __builtin_amdgcn_exp2f(s[vg][st][r]);
+        else s[vg][st][r] = __builtin_amdgcn_exp2f(fmaf(s[vg][st][r], c, -m_new));
         if ((e & 1) == 1) {
           const int k2 = r >> 3, w = (r & 7) >> 1;
           unsigned pw = pack2<DT>(s[vg][st][r - 1], s[vg][st][r]);
@@ -506,13 +627,13 @@ __global__ __launch_bounds__(256, 2) void attn3_kernel(const AttnParams p) {
   int st_cur = 0, st_prev = 2, st_next = 1;         // ring stage of tile t, t-1, t+1
   for (int t = 0; t < T; ++t) {
     // slot A: softmax(a, t) || P.V(b, t-1) [stage of t-1; all zeros for t = 0] + K.Q^T(b, t)
-    slot(AIC<0>{}, smem + st_cur * STG, smem + st_prev * STG + KSZ);
+    slot(AIC<0>{}, smem + st_cur * STG, smem + st_prev * STG + KSZ, t == 0);
     // tile t+1 landed (own DMA, then the barrier publishes everyone's); every wave is past its last read of tile t-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 2 < T) issue_dma(t + 2, st_prev);
     // slot B: softmax(b, t) || P.V(a, t) + K.Q^T(a, t+1)   (for t = T-1 the K.Q^T reads a stale stage; its result is unused)
-    slot(AIC<1>{}, smem + st_next * STG, smem + st_cur * STG + KSZ);
+    slot(AIC<1>{}, smem + st_next * STG, smem + st_cur * STG + KSZ, t == 0);
     const int tmp = st_prev; st_prev = st_cur; st_cur = st_next; st_next = tmp;
   }
   // epilogue: P.V(b, T-1)
@@ -559,8 +680,11 @@ int launch_attn2(const AttnParams& p, int B, hipStream_t s) {
   dim3 grid((p.nq + 255) / 256, p.H, B), block(256);
 #define IDF_ATTN2_CASE(KS, MT) \
   if (p.d == 8 * (2 * KS - 1)) { \
-    if (idf_attn2_mode() >= 2) hipLaunchKernelGGL((attn3_kernel<DT, KS, MT>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((attn2_kernel<DT, KS, MT>), grid, block, 0, s, p); \
+    const int mode = idf_attn2_mode(); \
+    if (mode == 2) hipLaunchKernelGGL((attn3_kernel<DT, KS, MT, false>), grid, block, 0, s, p); \
+    else if (mode == 4) hipLaunchKernelGGL((attn3_kernel<DT, KS, MT, true>), grid, block, 0, s, p); \
+    else if (mode == 3) hipLaunchKernelGGL((attn2_kernel<DT, KS, MT, true>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((attn2_kernel<DT, KS, MT, false>), grid, block, 0, s, p); \
     return idf_launch_status(); }
   IDF_ATTN2_CASE(2, 1)    // d = 24
   IDF_ATTN2_CASE(3, 2)    // d = 40

@@ -473,7 +473,7 @@ def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
 # ---------------------------------------------------------------------------------------------------
 # attention variant 2 (attention2.hip: 64 queries per wave, LDS-DMA staging), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2], ids=["v2", "v3-pipelined"])
+@pytest.fixture(params=[1, 2, 3, 4], ids=["v2", "v3-pipelined", "v2-lazy", "v3-pipelined-lazy"])
 def attn2(request):
     from instancediffusion_amd import _lib
     lib = _lib.load()

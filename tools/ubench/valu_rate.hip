@@ -32,6 +32,12 @@ __global__ void k(float* out, unsigned long long* cyc, float seed) {
         if (OP == 8) asm volatile("v_exp_f16 %0, %0" : "+v"(a[i]));
         if (OP == 9) asm volatile("v_sub_f32 %0, %0, %0" : "+v"(a[i]));
         if (OP == 10) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i & 3], 0, 0, 0);
+        if (OP == 11 || OP == 12 || OP == 13) {       // co-issue test: every 4th slot an MFMA, the others VALU
+          if ((i & 3) == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[(i >> 2) & 1]) : "v"(fa), "v"(fb));
+          else if (OP == 11) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+          else if (OP == 12) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i]));
+          else asm volatile("v_cvt_pk_bf16_f32 %0, %0, %0" : "+v"(a[i]));
+        }
       }
     }
   }
@@ -63,7 +69,7 @@ template <int OP> void run(const char* name) {
   }
 }
 int main() {
-  run<10>("mfma_32x32x16_bf16"); run<1>("v_fma_f32"); run<0>("v_exp_f32"); run<2>("v_max3_f32"); run<3>("v_cvt_pk_bf16_f32"); run<4>("v_permlane32_swap");
+  run<10>("mfma_32x32x16_bf16"); run<11>("1 mfma + 3 v_exp"); run<12>("1 mfma + 3 v_fma"); run<13>("1 mfma + 3 v_cvt_pk"); run<1>("v_fma_f32"); run<0>("v_exp_f32"); run<2>("v_max3_f32"); run<3>("v_cvt_pk_bf16_f32"); run<4>("v_permlane32_swap");
   run<5>("v_pk_fma_f32"); run<6>("v_pk_mul_f32"); run<7>("v_mul_f32"); run<8>("v_exp_f16"); run<9>("v_sub_f32");
   return 0;
 }

@@ -173,9 +173,12 @@ def measure_roofline(engine, batch):
     total_ms = sum(d["ms"] for d in agg.values())
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     name, d = dom
-    kern = {"conv3x3": "gemm_kernel<.., CONV=true> (implicit-GEMM 3x3 conv, 2-deep register prefetch)",
-            "gemm": "gemm_kernel_dma<.., CONV=false> (dense GEMM, LDS-DMA staging; 128x128 and 128x64 tiles)",
-            "attention": "attn_kernel"}.get(name, name)
+    kern = {"conv3x3": "gemm_kernel_big<.., CONV=true> (persistent 256x320 implicit-GEMM 3x3 conv, LDS-DMA gather; "
+                       "gemm_kernel<..,true> + split-K below 8^2)",
+            "gemm": "gemm_kernel_big<.., CONV=false> (persistent 256x{320,256}-tile dense GEMM, LDS-DMA staging, in-register "
+                    "epilogue; gemm_kernel_dma 128x128 for batched / badly quantised shapes)",
+            "attention": "attn2_kernel<.., LAZY> (64 queries/wave, LDS-DMA K/V^T, lazy rescaling) / attn_kernel for d=80,160"
+            }.get(name, name)
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     return dict(bound="mfma", kernel=kern, achieved=round(achieved, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
                 frac=round(achieved / PEAK_MFMA_TF, 4), traffic=pmc_traffic(name, batch),

@@ -46,10 +46,12 @@ const char* idf_build_info(void);
  * results are identical up to fp32 summation order).  Returns the previous value, or IDF_E_ARG for an unknown knob.
  *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256}-tile GEMM/conv kernel, 1 = automatic
  *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default.
+ *   IDF_TUNE_GEMM_GEOM: geometry of that kernel: 0 = one 8-wave workgroup per CU on 256-row tiles (64-deep K-tiles, 2 LDS
+ *   stages), 1 = two independent 4-wave workgroups per CU on 128-row tiles (32-deep K-tiles, 3 / 2 stages).  Env IDF_GEMM_GEOM.
  *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; otherwise, when the shape qualifies, the
  *   64-queries-per-wave LDS-DMA kernel: 1 = classic online softmax, 2 = software-pipelined form (softmax of one query
  *   group beside the MFMAs of the other), 3 = lazy rescaling (default: fastest), 4 = pipelined + lazy (d in {24,40,56}, n0 % 8 == n1 % 8 == 0).  Initial value: env IDF_ATTN2 or default. */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1 };
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_GEOM = 2 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1 };

@@ -28,8 +28,7 @@ namespace {
 
 __device__ __attribute__((aligned(128))) unsigned short idf_zero_page[64];   // zero-initialised device memory
 
-constexpr int BM = 256, WM = 64, TM = 2, RS = 64;
-constexpr int STAGE = 36864;                 // elements per pipeline stage: 73728 B = (256+320)*64*2
+constexpr int WM = 64, TM = 2;                // wave tile: 64 rows x BN/2 columns
 
 template <int I> struct IC { static constexpr int value = I; };
 template <int I, int N, int STEP, class F> __device__ __forceinline__ void static_for(F&& f) {
@@ -39,11 +38,21 @@ template <int I, int N, int STEP, class F> __device__ __forceinline__ void stati
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int DT, int BN, bool CONV>
-__global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
+// Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
+//   <256, BN, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages).
+//   <128, BN, 32, 3|2>: TWO independent 4-wave workgroups per CU (their barriers, DMA waits and epilogues interleave on
+//   the SIMDs instead of coinciding); 64-B LDS rows, 16-B slot ^= (row >> 2) & 3.
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV>
+__global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
   constexpr int WN = BN / 2, TN = WN / 32;
-  constexpr int W_INST = BN / 64, A_INST = BM / 64;        // LDS-DMA instructions (8 rows x 128 B each) per wave per K-tile
-  static_assert((BM + BN) * RS <= STAGE, "stage too small");
+  constexpr int NW = BM / 32;                              // waves per workgroup (8 or 4)
+  constexpr int RS = BKT;                                  // LDS row stride (elements): linear rows, no padding
+  constexpr int CPR = BKT / 8;                             // 16-B chunks per row (8 or 4)
+  constexpr int RPI = 64 / CPR;                            // rows moved by one LDS-DMA wave instruction (8 or 16)
+  constexpr int W_INST = BN / (RPI * NW), A_INST = BM / (RPI * NW);   // LDS-DMA instructions per wave per K-tile
+  constexpr int DPW = W_INST + A_INST;
+  constexpr int STAGE = (BM + BN) * RS;                    // elements per pipeline stage
+  static_assert(BN % (RPI * NW) == 0 && BM % (RPI * NW) == 0, "tile rows must split evenly over the DMA instructions");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
 
   const int tid = threadIdx.x;
@@ -55,10 +64,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
   // [x*G/8, (x+1)*G/8) of the n-fastest list, so tiles sharing an activation m-tile / weight n-tile share an L2.
   const int slot = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int tiles_n = p.N / BN;
-  const int nk = p.K / BK;
+  const int nk = p.K / BKT;
 
   // ---------------- loader state (runs one K-tile ahead of the MFMAs, across output-tile boundaries)
-  const int dr = lane >> 3, dc = lane & 7;
+  const int dr = lane / CPR, dc = lane % CPR;
+  auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };   // conflict-free ds_read_b128 (see header)
   unsigned woff[W_INST], aoff[A_INST];
   int ayx[A_INST];                                        // conv: (yo*stride-1) << 16 | (xo*stride-1) & 0xffff
   int l_seq, l_kt = 0, tap = 0, ci0 = 0;
@@ -68,14 +78,14 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
     const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
 #pragma unroll
     for (int j = 0; j < W_INST; ++j) {
-      const int row = 8 * (wave + 8 * j) + dr;
-      woff[j] = (unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)((dc ^ ((row >> 1) & 7)) * 8);
+      const int row = RPI * (wave + NW * j) + dr;
+      woff[j] = (unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)((dc ^ swz(row)) * 8);
     }
 #pragma unroll
     for (int j = 0; j < A_INST; ++j) {
-      const int row = 8 * (wave + 8 * j) + dr;
+      const int row = RPI * (wave + NW * j) + dr;
       const int m = min(m0 + row, p.M - 1);
-      const unsigned sw = (unsigned)((dc ^ ((row >> 1) & 7)) * 8);
+      const unsigned sw = (unsigned)((dc ^ swz(row)) * 8);
       if (CONV) {
         const int hw = p.Ho * p.Wo;
         const int b = m / hw, rem = m - b * hw;
@@ -93,10 +103,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
   auto issue_dma = [&](int stage) {                       // enqueue K-tile l_kt of tile l_seq into `stage`, then advance
     unsigned short* Al = smem + stage * STAGE;
     unsigned short* Wl = Al + BM * RS;
-    const unsigned short* Wk = p.W + (size_t)l_kt * BK;
+    const unsigned short* Wk = p.W + (size_t)l_kt * BKT;
 #pragma unroll
     for (int j = 0; j < W_INST; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wk + woff[j]), (lptr_t)(Wl + 8 * (wave + 8 * j) * RS), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wk + woff[j]), (lptr_t)(Wl + RPI * (wave + NW * j) * RS), 16, 0, 0);
     if (CONV) {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
@@ -108,15 +118,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
         const int ys = yi >> p.up, xs = xi >> p.up;
         const unsigned short* src = ok ? Ak + (aoff[j] + (unsigned)(ys * p.Win + xs) * (unsigned)p.lda)
                                        : idf_zero_page + dc * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Al + 8 * (wave + 8 * j) * RS), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Al + RPI * (wave + NW * j) * RS), 16, 0, 0);
       }
-      ci0 += BK;
+      ci0 += BKT;
       if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
     } else {
-      const unsigned short* Ak = p.A + (size_t)l_kt * BK;
+      const unsigned short* Ak = p.A + (size_t)l_kt * BKT;
 #pragma unroll
       for (int j = 0; j < A_INST; ++j)
-        __builtin_amdgcn_global_load_lds((gptr_t)(Ak + aoff[j]), (lptr_t)(Al + 8 * (wave + 8 * j) * RS), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ak + aoff[j]), (lptr_t)(Al + RPI * (wave + NW * j) * RS), 16, 0, 0);
     }
     if (++l_kt == nk) {
       l_kt = 0;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
 
   // ---------------- MFMA side
   f32x16 acc[TN][TM];
-  const int f_sw = (l31 >> 1) & 7;
+  const int f_sw = swz(l31);                              // fragment rows are (multiple of 32) + l31
   auto compute = [&](int stage) {
     const unsigned short* Al = smem + stage * STAGE;
     const unsigned short* Wl = Al + BM * RS;
@@ -142,9 +152,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
       for (int b = 0; b < TM; ++b) af[0][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + s8);
     }
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < BKT / 16; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < BK / 16) {
+      if (ks + 1 < BKT / 16) {
         const int s8 = (((ks + 1) * 2 + hi) ^ f_sw) * 8;
 #pragma unroll
         for (int a = 0; a < TN; ++a) wf[nxt][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + s8);
@@ -162,8 +172,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
   if (seq >= tiles_total) return;
   l_seq = seq;
   setup_loader(l_seq);
-  issue_dma(0);
-  int it = 0;
+  // prologue: NSTG-1 K-tiles of the flattened (tile, k) stream in flight
+  int issued = 0;                                         // K-tiles enqueued so far
+#pragma unroll
+  for (int j = 0; j < NSTG - 1; ++j)
+    if (l_seq < tiles_total) { issue_dma(j); ++issued; }
+  int it = 0, st_it = 0;                                  // K-tile consumed next and its ring stage
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
 
@@ -176,14 +190,24 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     for (int kt = 0; kt < nk; ++kt) {
-      // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's
-      // vmcnt wait followed by a barrier (hipcc does not add the wait to a barrier at the loop head by itself)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                    // ... and every wave has finished reading stage (it+1)&1
-      if (l_seq < tiles_total) issue_dma((it + 1) & 1);
-      compute(it & 1);
+      // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt
+      // wait followed by a barrier.  In steady state the NSTG-2 younger K-tiles stay in flight across the barrier
+      // (counted wait; VM ops retire in order); at the tail of the stream fewer are outstanding -> wait for all.
+      if (NSTG > 2 && issued - it == NSTG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * DPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // ... and every wave has finished reading the stage refilled below
+      asm volatile("" ::: "memory");
+      if (l_seq < tiles_total) {
+        int st_fill = st_it + NSTG - 1;
+        if (st_fill >= NSTG) st_fill -= NSTG;
+        issue_dma(st_fill);
+        ++issued;
+      }
+      compute(st_it);
       ++it;
+      if (++st_it == NSTG) st_it = 0;
     }
+
     // ---------------- epilogue of tile seq: no LDS, no barrier -- a wave that finishes its MFMAs early runs its epilogue
     // while the other wave of its SIMD is still in the K-loop.
     // acc[a][b][4q+e] = D[n = a*32 + 8q + 4hi + e][m = b*32 + l31].  Two v_permlane32_swap per register pair
@@ -291,27 +315,33 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(const CoreParams p, const
 }
 
 int g_num_cu = 0;
+int g_geom = -2;                                             // 0: one 8-wave 256-row workgroup per CU, 1: two 4-wave 128-row ones
 
-template <int DT, int BN, bool CONV>
+int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cu = n;
+  }
+  return g_num_cu;
+}
+
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV>
 int launch_big_cfg(const CoreParams& p, hipStream_t s) {
-  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BN, CONV>;
-  constexpr int smem = 2 * STAGE * 2;
+  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV>;
+  constexpr int smem = NSTG * (BM + BN) * BKT * 2;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  if (g_num_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    g_num_cu = n;
-  }
   CoreParams q = p;
-  q.splitk = 1; q.kt_per_slice = p.K / BK;
+  q.splitk = 1; q.kt_per_slice = p.K / BKT;
   const int tiles = (p.N / BN) * ((p.M + BM - 1) / BM);
-  const int grid = tiles < g_num_cu ? tiles : g_num_cu;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, q, tiles);
+  const int slots = num_cu() * (BM == 128 ? 2 : 1);
+  const int grid = tiles < slots ? tiles : slots;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BM * 2), smem, s, q, tiles);
   return idf_launch_status();
 }
 
@@ -319,7 +349,13 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s) {
 
 long long idf_stat_big_launches = 0;
 
-// Shape gate + tile-width choice.  `force` (IDF_GEMM_VARIANT=4) skips the occupancy heuristic, not the shape rules.
+int idf_big_geom() {
+  if (g_geom == -2) { const char* e = getenv("IDF_GEMM_GEOM"); g_geom = e ? atoi(e) : IDF_GEMM_GEOM_DEFAULT; }
+  return g_geom;
+}
+int idf_big_set_geom(int v) { const int prev = idf_big_geom(); g_geom = v; return prev; }
+
+// Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
 int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s) {
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
   if (p.K < 2 * BK || (p.K % BK) != 0) return IDF_BIG_UNSUPPORTED;
@@ -335,16 +371,14 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   else if (p.N % 320 == 0) bn = 320;
   else if (p.N % 256 == 0) bn = 256;
   if (!bn) return IDF_BIG_UNSUPPORTED;
-  if (g_num_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    g_num_cu = n;
-  }
-  const long long tiles = (long long)(p.N / bn) * ((p.M + BM - 1) / BM);
+  const int geom = idf_big_geom();
+  const int bm = geom == 1 ? 128 : 256;
+  const long long slots = (long long)num_cu() * (geom == 1 ? 2 : 1);
+  const long long tiles = (long long)(p.N / bn) * ((p.M + bm - 1) / bm);
   if (!force) {
-    // tile quantisation: one persistent workgroup per CU processes ceil(tiles / CUs) tiles
-    const long long rounds = (tiles + g_num_cu - 1) / g_num_cu;
-    const double eff = (double)tiles / (double)(rounds * g_num_cu);
+    // tile quantisation: a persistent workgroup slot processes ceil(tiles / slots) tiles
+    const long long rounds = (tiles + slots - 1) / slots;
+    const double eff = (double)tiles / (double)(rounds * slots);
     if (eff < 0.80) return IDF_BIG_UNSUPPORTED;
   }
   {                                                       // the loader uses 32-bit element offsets
@@ -352,9 +386,13 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
     if (rows * (unsigned long long)p.lda >= (1ull << 31) || (unsigned long long)p.N * p.ldw >= (1ull << 31)) return IDF_BIG_UNSUPPORTED;
   }
   ++idf_stat_big_launches;
-#define IDF_BIG_DISPATCH(DT)                                                                                   \
-  if (conv) return bn == 320 ? launch_big_cfg<DT, 320, true>(p, s) : launch_big_cfg<DT, 256, true>(p, s);      \
-  return bn == 320 ? launch_big_cfg<DT, 320, false>(p, s) : launch_big_cfg<DT, 256, false>(p, s);
+#define IDF_BIG_DISPATCH(DT)                                                                                              \
+  if (geom == 1) {                                                                                                        \
+    if (conv) return bn == 320 ? launch_big_cfg<DT, 128, 320, 32, 2, true>(p, s) : launch_big_cfg<DT, 128, 256, 32, 3, true>(p, s);   \
+    return bn == 320 ? launch_big_cfg<DT, 128, 320, 32, 2, false>(p, s) : launch_big_cfg<DT, 128, 256, 32, 3, false>(p, s);           \
+  }                                                                                                                       \
+  if (conv) return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, true>(p, s) : launch_big_cfg<DT, 256, 256, 64, 2, true>(p, s);     \
+  return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, false>(p, s) : launch_big_cfg<DT, 256, 256, 64, 2, false>(p, s);
   if (dtype == IDF_BF16) { IDF_BIG_DISPATCH(IDF_BF16) }
   if (dtype == IDF_F16) { IDF_BIG_DISPATCH(IDF_F16) }
 #undef IDF_BIG_DISPATCH

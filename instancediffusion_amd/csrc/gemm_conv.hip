@@ -595,6 +595,10 @@ extern "C" int idf_set_tuning(int knob, int value) {
     g_big_mode = value;
     return prev;
   }
+  if (knob == IDF_TUNE_GEMM_GEOM) {
+    if (value < 0 || value > 1) return IDF_E_ARG;
+    return idf_big_set_geom(value);
+  }
   if (knob == IDF_TUNE_ATTN2) {
     if (value < 0 || value > 4) return IDF_E_ARG;
     return idf_attn2_set_mode(value);

@@ -100,5 +100,10 @@ __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, in
 
 // Big-tile persistent kernel (gemm_big.hip).  Returns IDF_BIG_UNSUPPORTED when the shape does not qualify.
 #define IDF_BIG_UNSUPPORTED (-100)
+#ifndef IDF_GEMM_GEOM_DEFAULT
+#define IDF_GEMM_GEOM_DEFAULT 0
+#endif
 extern long long idf_stat_big_launches;
+int idf_big_geom();
+int idf_big_set_geom(int v);
 int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s);

@@ -150,11 +150,14 @@ class PLMSSamplerInst(_PLMSBase):
     """Multi-instance Sampler, plms_instance.py:7-212."""
 
     def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None, mis=0.0,
-                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 32):
+                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 32,
+                 unit_sharding: str = "auto"):
         super().__init__(diffusion, model, schedule, alpha_generator_func, set_alpha_scale)
         self.mis = mis
         self.crop_and_paste_latents = crop_and_paste_latents      # hard-coded False in the reference (:128)
         self.shard_across_ranks = shard_across_ranks
+        assert unit_sharding in ("auto", "image", "instance")
+        self.unit_sharding = unit_sharding
         self.max_units = max_units
 
     @torch.no_grad()
@@ -206,9 +209,19 @@ class PLMSSamplerInst(_PLMSBase):
             return torch.tensor(r, device=dev, dtype=torch.long)
 
         # ---------------- phase 1: N+1 independent trajectories per image (plms_instance.py:86-104) ----------
-        # work unit = (instance j, image b), owned by rank (b + j) % world; the owner of image b (rank b % world)
-        # therefore also runs (0, b), whose eps history continues into phase 2.
-        units = [(j, b) for j in range(n_all) for b in range(B) if (b + j) % world == rank]
+        # work unit = (instance j, image b).  "image" sharding: owner = b % world -- every trajectory of an image lives on
+        # the rank that also runs its phase 2, the first-evaluation hoist touches only this rank's images and per-rank work
+        # is independent of the world size (weak scaling); used when the images divide evenly over the ranks.
+        # "instance" sharding: owner = (b + j) % world -- spreads the N+1 trajectories of FEW images (B < world, e.g. one
+        # image on 8 GPUs) over the ranks; the owner of image b (rank b % world) still runs (0, b), whose eps history
+        # continues into phase 2.  Either way the merge is one small all-reduce.
+        mode = self.unit_sharding
+        if mode == "auto":
+            mode = "image" if (B % world == 0) else "instance"
+        if mode == "image":
+            units = [(j, b) for j in range(n_all) for b in range(B) if b % world == rank]
+        else:
+            units = [(j, b) for j in range(n_all) for b in range(B) if (b + j) % world == rank]
         # Reference quirk: restore_first_conv_from_SD is never undone, so if alpha hits 0 inside phase 1 the LATER
         # instances would run their EARLY steps with the swapped conv.  Only then is the serial order observable;
         # reproduce it by advancing one instance at a time.

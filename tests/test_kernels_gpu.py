@@ -353,16 +353,18 @@ def test_convnext_pieces(ops, ref):
 # ---------------------------------------------------------------------------------------------------
 # persistent big-tile GEMM / conv kernel (gemm_big.hip), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture()
-def big():
-    """Force the 256 x {320,256}-tile kernel for every qualifying shape; yields a callable returning how many launches
-    it served since the fixture started (so a test cannot pass on the 128x128 kernels by accident)."""
+@pytest.fixture(params=[0, 1], ids=["1x8waves-256rows", "2x4waves-128rows"])
+def big(request):
+    """Force the persistent big-tile kernel (in both geometries) for every qualifying shape; yields a callable returning
+    how many launches it served since the fixture started (so a test cannot pass on the 128x128 kernels by accident)."""
     from instancediffusion_amd import _lib
     lib = _lib.load()
     prev = lib.idf_set_tuning(0, 2)
+    prev_geom = lib.idf_set_tuning(2, request.param)
     start = lib.idf_get_stat(0)
     yield lambda: lib.idf_get_stat(0) - start
     lib.idf_set_tuning(0, prev)
+    lib.idf_set_tuning(2, prev_geom)
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (4113, 640, 1280), (300, 512, 256), (256, 1280, 128),

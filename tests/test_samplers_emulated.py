@@ -86,14 +86,14 @@ def test_mis_serial_quirk_and_crop_paste_vs_oracle():
     assert cases.rel_rms(out, want) < 5e-3
 
 
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, sharding="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gold, meta, inp, model, gi, diffusion = setup("tiny_box")
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
-                              set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+                              set_alpha_scale=set_alpha_scale, mis=meta["mis"], unit_sharding=sharding)
     out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
                          guidance_scale=7.5)
     # by value (numpy): a torch tensor would travel as a shared-memory handle that dies with this process
@@ -102,13 +102,15 @@ def _dist_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_mis_sharded_world2_gloo():
-    """N>1 path: (instance, image) units sharded over 2 ranks + all-reduce merge + image-sharded phase 2."""
+@pytest.mark.parametrize("sharding", ["image", "instance"])
+def test_mis_sharded_world2_gloo(sharding):
+    """N>1 path: (instance, image) units sharded over 2 ranks (both ownership rules) + all-reduce merge + image-sharded
+    phase 2."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500)
-    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + (7 if sharding == "image" else 0)
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q, sharding)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])

@@ -544,3 +544,82 @@ def test_attention_v2_matches_v1(ops, attn2):
     _lib.load().idf_set_tuning(1, mode)
     assert attn2() == 1
     assert relmax(o2, o1) < BF16_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE shapes: 64-row forward batch at the 64x64 latent): no oracle needed
+# ---------------------------------------------------------------------------------------------------
+FULL_B = 16          # rows of the property checks (the kernels see M = FULL_B * 4096 = 65536 token rows)
+
+
+def test_full_size_gemm_identity_and_linearity(ops):
+    """W = I reproduces A exactly (every output is ONE product), and GEMM(a1 + a2) == GEMM(a1) + GEMM(a2) on integer data."""
+    M, C = FULL_B * 4096, 320
+    g = torch.Generator().manual_seed(70)
+    a = torch.randint(-8, 9, (M, C), generator=g).to(torch.bfloat16)
+    eye = torch.eye(C).to(torch.bfloat16)
+    out = ops.gemm(dev(a), dev(eye), ops.empty((M, C)))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), a)
+    w = torch.randint(-2, 3, (640, C), generator=g).to(torch.bfloat16)
+    a2 = torch.randint(-8, 9, (M, C), generator=g).to(torch.bfloat16)
+    o1 = ops.gemm(dev(a), dev(w), ops.empty((M, 640), torch.float32))
+    o2 = ops.gemm(dev(a2), dev(w), ops.empty((M, 640), torch.float32))
+    o12 = ops.gemm(dev(a + a2), dev(w), ops.empty((M, 640), torch.float32))
+    torch.cuda.synchronize()
+    assert torch.equal(o12, o1 + o2)
+
+
+def test_full_size_conv3x3_taps_are_shifts(ops):
+    """A 3x3 kernel that is 1 on one tap (identity over channels) shifts the image by that tap with zero padding -- exact."""
+    from instancediffusion_amd.engine import pack_conv3x3
+    B, H, C = FULL_B, 64, 320
+    g = torch.Generator().manual_seed(71)
+    x = torch.randint(-8, 9, (B, H, H, C), generator=g).to(torch.bfloat16)
+    dx = dev(x)
+    for (ky, kx) in [(1, 1), (0, 0), (2, 1), (1, 2)]:
+        w4 = torch.zeros(C, C, 3, 3)
+        w4[torch.arange(C), torch.arange(C), ky, kx] = 1.0
+        out = ops.conv3x3(dx, dev(to16(pack_conv3x3(w4))), ops.empty((B, H, H, C)))
+        torch.cuda.synchronize()
+        want = torch.zeros_like(x)
+        dy, dxx = ky - 1, kx - 1                           # out[y][x] = in[y + dy][x + dxx]
+        ys, xs = slice(max(0, -dy), H - max(0, dy)), slice(max(0, -dxx), H - max(0, dxx))
+        yd, xd = slice(max(0, dy), H - max(0, -dy)), slice(max(0, dxx), H - max(0, -dxx))
+        want[:, ys, xs] = x[:, yd, xd]
+        assert torch.equal(out.cpu(), want), (ky, kx)
+
+
+def test_full_size_attention_rows_sum_to_one(ops):
+    """V = 1 everywhere: every output element is sum_j softmax_j = 1, for the self- and the two-segment (gated) form."""
+    B, H, d, N = 2, 8, 40, 4096
+    C = H * d
+    q, k = to16(gen((B, N, C), 72)), to16(gen((B, N, C), 73))
+    vt = torch.ones(B, C, N, dtype=torch.bfloat16)
+    out = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
+    k1, vt1 = to16(gen((B, 184, C), 74)), torch.zeros(B, C, 192, dtype=torch.bfloat16)
+    vt1[:, :, :184] = 1.0
+    out2 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H, k1=dev(k1), vt1=dev(vt1), n1=184)
+    torch.cuda.synchronize()
+    for o in (out, out2):
+        assert float((o.float() - 1.0).abs().max()) <= 2.0 ** -7
+
+
+def test_full_size_scaleu_identity_settings(ops):
+    """hscale = 1 and sm1 = 0 make ScaleU a pure concat: bit-exact copy of both inputs."""
+    B, H, C = FULL_B, 64, 320
+    h, skip = to16(gen((B, H, H, C), 75)), to16(gen((B, H, H, C), 76))
+    out = ops.scaleu_concat(dev(h), dev(skip), ops.empty((B, H, H, 2 * C)), dev(torch.ones(C)), dev(torch.zeros(1)))
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., :C].cpu(), h) and torch.equal(out[..., C:].cpu(), skip)
+
+
+def test_full_size_groupnorm_moments(ops):
+    """gamma = 1, beta = 0, no SiLU: every (sample, group) of the output has mean 0 and variance 1."""
+    B, HW, C = FULL_B, 4096, 320
+    x = to16(gen((B, HW, C), 77) * 3.0 + 1.5)
+    out = ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(torch.ones(C)), dev(torch.zeros(C)), 1e-5, False)
+    torch.cuda.synchronize()
+    o = out.float().view(B, HW, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+    assert float(o.mean(-1).abs().max()) < 2e-3
+    assert float((o.var(-1, unbiased=False) - 1.0).abs().max()) < 5e-3

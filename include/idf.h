@@ -171,6 +171,19 @@ int idf_plms_update(const float* x, const float* e_t, const float* e1, const flo
 int idf_mis_merge(const float* lat, const int* boxes, float* out, int n_inst, int B, int C, int H, int W,
                   int mode, void* stream);
 
+/* ---- VAE decoder pieces (AutoencoderKL.decode, the step right after the sampling path) --------
+ * idf_softmax_rows: p[r][0:n] = softmax(scale * s[r][0:n]) for `rows` stacked rows (row r at s + r*lds / p + r*ldp);
+ * s fp32, p 16-bit.  Replaces the torch.bmm -> softmax of the single-head 512-channel AttnBlock
+ * (ldm/modules/diffusionmodules/model.py:185-189): the scores come from idf_gemm(.., IDF_EPI_OUT_F32), this kernel
+ * normalises them, a second idf_gemm applies V (:194).  n % 4 == 0, lds % 4 == 0, ldp % 4 == 0, scale > 0.
+ * idf_pointwise_nchw: 1x1 conv between small channel counts (Cin <= 16) on fp32 NCHW, input pre-scaled by in_scale:
+ * AutoencoderKL.decode's `1/scale_factor * z` + post_quant_conv (ldm/models/autoencoder.py:32-35).  bias may be NULL.
+ * (The decoder's other layers are idf_conv_in / idf_groupnorm / idf_conv3x3 / idf_gemm calls.)                          */
+int idf_softmax_rows(const float* s, void* p, long long rows, int n, long long lds, long long ldp, float scale,
+                     int dtype, void* stream);
+int idf_pointwise_nchw(const float* x, const float* w /*[Cout][Cin]*/, const float* bias, float* out, int B, int Cin,
+                       int Cout, long long HW, float in_scale, void* stream);
+
 /* ---- layout helpers ---------------------------------------------------------------------------------------*/
 int idf_cast_f32_to_16(const float* x, void* out, long long n, int dtype, void* stream);
 

@@ -66,6 +66,8 @@ SYMBOLS = {
     "idf_plms_update": (ci, [vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, vp, ll, vp]),
     "idf_mis_merge": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "idf_cast_f32_to_16": (ci, [vp, vp, ll, ci, vp]),
+    "idf_softmax_rows": (ci, [vp, vp, ll, ci, ll, ll, cf, ci, vp]),
+    "idf_pointwise_nchw": (ci, [vp, vp, vp, vp, ci, ci, ci, ll, cf, vp]),
 }
 
 _lib = None

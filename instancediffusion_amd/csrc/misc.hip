@@ -148,6 +148,65 @@ __global__ void cast_kernel(const float* __restrict__ x, unsigned short* __restr
   if (i < n) out[i] = Elem<DT>::from_f32(x[i]);
 }
 
+// Row softmax of an fp32 score matrix into 16-bit probabilities: p[r][j] = exp(scale*(s[r][j] - max_j s[r][:])) / sum.
+// Used by the single-head, head-dim-512 attention of the VAE decoder mid block (model.py:178-196), whose head dim is
+// beyond the register budget of the flash kernels: there the scores come from one batched MFMA GEMM (fp32 out), this
+// kernel normalises them, and a second GEMM applies V.  One 256-thread workgroup per row; the row (n*4 bytes, 16 KB at
+// n = 4096) is read three times (max, sum, write), passes 2 and 3 from L2.  HBM-bound: 4 B read + 2 B written / score.
+template <int DT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, unsigned short* __restrict__ p,
+                                                          int n, long long lds, long long ldp, float scale_log2e) {
+  __shared__ float red[8];
+  const float* sr = s + (size_t)blockIdx.x * (size_t)lds;
+  unsigned short* pr = p + (size_t)blockIdx.x * (size_t)ldp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n4 = n >> 2;
+  float m = -3.0e38f;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(sr)[i];
+    m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float mb = m * scale_log2e;                              // scale > 0: max of the scaled row
+  float sum = 0.f;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(sr)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += __builtin_amdgcn_exp2f(fmaf(v[j], scale_log2e, -mb));
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = 1.0f / sum;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(sr)[i];
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(fmaf(v[j], scale_log2e, -mb)) * inv;
+    *reinterpret_cast<u32x2*>(pr + 4 * i) = u32x2{pack2<DT>(e[0], e[1]), pack2<DT>(e[2], e[3])};
+  }
+}
+
+// 1x1 convolution between small channel counts on fp32 NCHW (AutoencoderKL.post_quant_conv, autoencoder.py:34-35,
+// with the 1/scale_factor of :33 folded in as in_scale): out[b][co][p] = bias[co] + sum_ci w[co][ci] * in_scale * x[b][ci][p].
+__global__ void pointwise_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                      float* __restrict__ out, int B, int Cin, int Cout, long long HW, float in_scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * HW) return;
+  const long long b = i / HW, pix = i - b * HW;
+  float xv[16];
+  for (int ci = 0; ci < Cin; ++ci) xv[ci] = x[(b * Cin + ci) * HW + pix] * in_scale;
+  for (int co = 0; co < Cout; ++co) {
+    float a = bias ? bias[co] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) a = fmaf(w[co * Cin + ci], xv[ci], a);
+    out[(b * Cout + co) * HW + pix] = a;
+  }
+}
+
 inline dim3 grid1d(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 }  // namespace
@@ -185,7 +244,17 @@ extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bia
   if (!aligned16(out)) return IDF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = (size_t)9 * Cin * Cout * sizeof(float);
-  if (smem > 64 * 1024) return IDF_E_UNSUPPORTED;
+  if (smem > 144 * 1024) return IDF_E_UNSUPPORTED;               // gfx950: 160 KB LDS per CU
+  if (smem > 64 * 1024) {                                        // e.g. the VAE decoder's 4 -> 512 first conv (72 KB)
+    static bool attr_set[2] = {false, false};
+    const int v = dtype == IDF_F16 ? 1 : 0;
+    if (!attr_set[v]) {
+      const void* fn = dtype == IDF_F16 ? (const void*)conv_in_kernel<IDF_F16> : (const void*)conv_in_kernel<IDF_BF16>;
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set[v] = true;
+    }
+  }
   const int ppb = 64;                                           // pixels per workgroup
   const long long npix = (long long)B * H * W;
   dim3 grid((unsigned)((npix + ppb - 1) / ppb));
@@ -228,5 +297,26 @@ extern "C" int idf_cast_f32_to_16(const float* x, void* out, long long n, int dt
   if (dtype == IDF_BF16) hipLaunchKernelGGL(cast_kernel<IDF_BF16>, grid1d(n), dim3(256), 0, s, x, (unsigned short*)out, n);
   else if (dtype == IDF_F16) hipLaunchKernelGGL(cast_kernel<IDF_F16>, grid1d(n), dim3(256), 0, s, x, (unsigned short*)out, n);
   else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
+extern "C" int idf_softmax_rows(const float* s, void* p, long long rows, int n, long long lds, long long ldp, float scale,
+                                int dtype, void* stream) {
+  if (!s || !p || rows <= 0 || n <= 0 || (n & 3) || lds < n || ldp < n || !(scale > 0.0f)) return IDF_E_ARG;
+  if (rows > 0x7fffffffLL) return IDF_E_ARG;
+  if ((lds & 3) || (ldp & 3) || !aligned16(s) || (((uintptr_t)p) & 7u)) return IDF_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const float sl2 = scale * 1.4426950408889634f;
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(softmax_rows_kernel<IDF_BF16>, dim3((unsigned)rows), dim3(256), 0, st, s, (unsigned short*)p, n, lds, ldp, sl2);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(softmax_rows_kernel<IDF_F16>, dim3((unsigned)rows), dim3(256), 0, st, s, (unsigned short*)p, n, lds, ldp, sl2);
+  else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
+extern "C" int idf_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                                  long long HW, float in_scale, void* stream) {
+  if (!x || !w || !out || B <= 0 || Cin <= 0 || Cin > 16 || Cout <= 0 || HW <= 0) return IDF_E_ARG;
+  hipLaunchKernelGGL(pointwise_nchw_kernel, grid1d((long long)B * HW), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, Cin,
+                     Cout, HW, in_scale);
   return idf_launch_status();
 }

@@ -260,3 +260,23 @@ class HipOps:
         _lib.check(self.lib.idf_cast_f32_to_16(_p(x_f32), _p(out), out.numel(), self.dt, self._stream()),
                    "idf_cast_f32_to_16")
         return out
+
+    def softmax_rows(self, s_f32, out, scale):
+        """s_f32 [.., R, n] fp32 (rows stacked contiguously), out same shape 16-bit: out = softmax(scale * s, -1)."""
+        assert s_f32.dtype == torch.float32 and s_f32.is_contiguous() and out.is_contiguous() and out.shape == s_f32.shape
+        n = s_f32.shape[-1]
+        rows = s_f32.numel() // n
+        _lib.check(self.lib.idf_softmax_rows(_p(s_f32), _p(out), rows, n, n, n, float(scale), self.dt, self._stream()),
+                   "idf_softmax_rows")
+        return out
+
+    def pointwise_nchw(self, x, w, bias, out, in_scale=1.0):
+        """fp32 NCHW 1x1 conv between small channel counts: out = w @ (in_scale * x) + bias."""
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = w.shape[0]
+        HW = x.numel() // (B * Cin)
+        for t in (x, w, out) + ((bias,) if bias is not None else ()):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(self.lib.idf_pointwise_nchw(_p(x), _p(w), _p(bias), _p(out), B, Cin, Cout, HW, float(in_scale),
+                                               self._stream()), "idf_pointwise_nchw")
+        return out

@@ -196,6 +196,45 @@ def gen_case(tag: str, cfg_name: str, variant: str, latent: int, n_boxes: int, b
     return schema
 
 
+# reduced VAE for fast tests: 64 base channels, 3 levels (x4 upsampling), the same block structure (mid attention incl.)
+VAE_VARIANTS = {
+    "full": {},
+    "tiny": dict(ch=64, ch_mult=[1, 2, 2], num_res_blocks=1),
+}
+
+
+@torch.no_grad()
+def gen_vae_case(tag: str, variant: str, latent: int, batch: int):
+    """AutoencoderKL.decode of the UNMODIFIED reference (ldm/models/autoencoder.py:32-36) on key-name-seeded weights."""
+    print(f"[golden] {tag}: autoencoder variant={variant} latent={latent}", flush=True)
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", "test_box.yaml")))["autoencoder"]
+    cfg["params"]["ddconfig"].update(VAE_VARIANTS[variant])
+    from ldm.util import instantiate_from_config
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("idf_synth", os.path.join(REPO, "instancediffusion_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    ae = instantiate_from_config(cfg).eval()
+    schema = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(synth.synth_state_dict(schema, salt=7), strict=True)
+    g = torch.Generator().manual_seed(4321)
+    z = torch.randn(batch, 4, latent, latent, generator=g) * 0.18215 * 4.0      # latents of a trained model: std ~ 0.18*O(1..5)
+    probes = {}
+    dec = ae.decoder
+    hooks = [dec.conv_in.register_forward_hook(lambda m, a, o: probes.__setitem__("conv_in", fp(o))),
+             dec.mid.attn_1.register_forward_hook(lambda m, a, o: probes.__setitem__("mid.attn_1", fp(o))),
+             dec.mid.block_2.register_forward_hook(lambda m, a, o: probes.__setitem__("mid.block_2", fp(o)))]
+    for i in range(dec.num_resolutions):
+        hooks.append(dec.up[i].block[-1].register_forward_hook(lambda m, a, o, i=i: probes.__setitem__(f"up.{i}", fp(o))))
+    img = ae.decode(z)
+    for h in hooks:
+        h.remove()
+    out = dict(meta=dict(tag=tag, variant=variant, latent=latent, batch=batch, z_fp=fp(z), salt=7),
+               img=img.clone(), probes=probes)
+    torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
+    return schema
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -216,6 +255,10 @@ def main():
     if args.only in ("all", "full"):
         schema = gen_case("full_box_c1", "test_box.yaml", "full", 64, 4, 1, boxes="c1", samplers=False)
         json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "unet_schema.json"), "w"))
+    if args.only in ("all", "vae"):
+        gen_vae_case("vae_tiny", "tiny", 8, 2)
+        schema = gen_vae_case("vae_full_16", "full", 16, 1)
+        json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "vae_schema.json"), "w"))
     print("done")
 
 

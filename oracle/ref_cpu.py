@@ -602,3 +602,58 @@ def plms_sample_mis(model: OracleModel, S: int, inputs: List[dict], uc, guidance
         if len(old_eps) >= 4:
             old_eps.pop(0)
     return img
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE decoder: ldm/models/autoencoder.py + ldm/modules/diffusionmodules/model.py
+# ------------------------------------------------------------------------------------------------
+# SD-1.5 KL-f8 autoencoder (configs/test_box.yaml:42-61)
+DEFAULT_VAE_CFG = dict(scale_factor=0.18215, embed_dim=4, z_channels=4, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                       attn_resolutions=(), resolution=256, out_ch=3)
+
+
+def vae_resnet_block(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """model.py:121-143 with temb None: GN(32, eps 1e-6) -> swish -> conv3x3, twice; 1x1 nin_shortcut if Cin != Cout."""
+    h = _conv(sd, p + ".conv1", silu(_gn32(sd, p + ".norm1", x, 1e-6)))
+    h = _conv(sd, p + ".conv2", silu(_gn32(sd, p + ".norm2", h, 1e-6)))
+    if (p + ".nin_shortcut.weight") in sd:
+        x = _conv(sd, p + ".nin_shortcut", x, padding=0)
+    return x + h
+
+
+def vae_attn_block(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """model.py:178-202: one head over the H*W positions, scale = C^-0.5, q/k/v/proj_out are 1x1 convs WITH bias."""
+    h = _gn32(sd, p + ".norm", x, 1e-6)
+    q, k, v = (_conv(sd, f"{p}.{n}", h, padding=0) for n in ("q", "k", "v"))
+    b, c, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)                       # b, hw, c
+    k = k.reshape(b, c, hh * ww)                                        # b, c, hw
+    w_ = torch.softmax(torch.bmm(q, k) * (int(c) ** (-0.5)), dim=2)     # w_[b,i,j] over keys j
+    v = v.reshape(b, c, hh * ww)
+    h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)         # h[b,c,i] = sum_j v[b,c,j] w_[b,i,j]
+    return x + _conv(sd, p + ".proj_out", h, padding=0)
+
+
+def vae_decode(sd: SD, cfg, z: torch.Tensor) -> torch.Tensor:
+    """AutoencoderKL.decode (autoencoder.py:32-36) + Decoder.forward (model.py:534-568): latent [B,4,H,W] ->
+    image [B,3,8H,8W] (for the 4-level config).  ``sd`` uses the reference key names (``decoder.*``,
+    ``post_quant_conv.*``)."""
+    nres = len(cfg["ch_mult"])
+    z = (1.0 / cfg["scale_factor"]) * z
+    z = _conv(sd, "post_quant_conv", z, padding=0)
+    h = _conv(sd, "decoder.conv_in", z)
+    h = vae_resnet_block(sd, "decoder.mid.block_1", h)
+    h = vae_attn_block(sd, "decoder.mid.attn_1", h)
+    h = vae_resnet_block(sd, "decoder.mid.block_2", h)
+    curr_res = cfg["resolution"] // 2 ** (nres - 1)
+    for i_level in reversed(range(nres)):
+        for i_block in range(cfg["num_res_blocks"] + 1):
+            h = vae_resnet_block(sd, f"decoder.up.{i_level}.block.{i_block}", h)
+            if curr_res in cfg["attn_resolutions"]:
+                h = vae_attn_block(sd, f"decoder.up.{i_level}.attn.{i_block}", h)
+        if i_level != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")      # model.py:53
+            h = _conv(sd, f"decoder.up.{i_level}.upsample.conv", h)
+            curr_res *= 2
+    h = silu(_gn32(sd, "decoder.norm_out", h, 1e-6))
+    return _conv(sd, "decoder.conv_out", h)

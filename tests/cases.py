@@ -66,3 +66,31 @@ def unet_schema(cfg: dict) -> Dict[str, tuple]:
 def rel_rms(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.double(); b = b.double()
     return float(((a - b).pow(2).mean() / b.pow(2).mean().clamp_min(1e-30)).sqrt())
+
+
+# ---- VAE decoder cases (oracle/make_golden.py:gen_vae_case) -------------------------------------------------------
+VAE_VARIANTS = {"full": dict(), "tiny": dict(ch=64, ch_mult=(1, 2, 2), num_res_blocks=1)}
+
+
+def vae_cfg_for(variant: str) -> dict:
+    cfg = dict(ref_cpu.DEFAULT_VAE_CFG)
+    cfg.update(VAE_VARIANTS[variant])
+    return cfg
+
+
+def build_vae(cfg: dict, salt: int = 7):
+    """Host AutoencoderKL mirror with key-name-seeded weights (the parameters make_golden gave the reference)."""
+    from ldm.models.autoencoder import AutoencoderKL
+    dd = dict(double_z=True, z_channels=cfg["z_channels"], resolution=cfg["resolution"], in_channels=3,
+              out_ch=cfg["out_ch"], ch=cfg["ch"], ch_mult=list(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"],
+              attn_resolutions=list(cfg["attn_resolutions"]), dropout=0.0)
+    with torch.device("meta"):
+        ae = AutoencoderKL(ddconfig=dd, embed_dim=cfg["embed_dim"], scale_factor=cfg["scale_factor"])
+    ae = ae.to_empty(device="cpu")
+    ae.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in ae.state_dict().items()}, salt))
+    return ae.eval()
+
+
+def vae_latent(meta: dict) -> torch.Tensor:
+    g = torch.Generator().manual_seed(4321)
+    return torch.randn(meta["batch"], 4, meta["latent"], meta["latent"], generator=g) * 0.18215 * 4.0

@@ -223,3 +223,17 @@ class EmulOps:
     def cast16(self, x_f32, out):
         out.copy_(x_f32)
         return out
+
+    def softmax_rows(self, s_f32, out, scale):
+        self._count("softmax_rows")
+        assert s_f32.dtype == torch.float32
+        out.copy_(torch.softmax(s_f32 * scale, -1))
+        return out
+
+    def pointwise_nchw(self, x, w, bias, out, in_scale=1.0):
+        self._count("pointwise_nchw")
+        y = torch.einsum("oc,bc...->bo...", w, x * in_scale)
+        if bias is not None:
+            y = y + bias.view(1, -1, *([1] * (x.dim() - 2)))
+        out.copy_(y)
+        return out

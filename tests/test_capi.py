@@ -40,6 +40,8 @@ def test_argument_validation_without_gpu():
     assert lib.idf_attention(ctypes.byref(t), None) == -1
     assert lib.idf_layernorm(None, 0, None, 0, None, None, 1, 8, 1e-5, 0, None) == -1
     assert lib.idf_groupnorm_ws_floats(2, 4096) == 2 * 64 * 32 * 2
+    assert lib.idf_softmax_rows(None, None, 4, 64, 64, 64, 1.0, 0, None) == -1
+    assert lib.idf_pointwise_nchw(None, None, None, None, 1, 4, 4, 16, 1.0, None) == -1
     with pytest.raises(_lib.IdfError):
         _lib.check(-2, "x")
 

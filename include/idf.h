@@ -102,7 +102,11 @@ int idf_conv_in(const float* x_nchw, const float* w /*[C][Cin][3][3]*/, const fl
  * the gated self-attention concatenates visual tokens and the 184 grounding tokens (attention.py:307) -- the
  * two-segment form never materialises the concatenation and only computes the N_visual query rows that
  * attention.py:308 keeps.  V is supplied TRANSPOSED: vt[b][h*d + e][j] (ld = ldv, padded to a multiple of 64).
- * d % 8 == 0, d <= 160.                                                                                      */
+ * d % 8 == 0, d <= 160.
+ * Optional instance-visibility mask (the reference's masked gated self-attention, attention.py:187-255, reached with
+ * efficient_attention=False + grounding_input["att_masks"]): 32-bit words per query / per key; query q may attend key j
+ * iff (qbits[b][q] & kbits{0,1}[b][j]) != 0, or j is q's own token in segment 0 (the reference's 1e-9 diagonal).
+ * qbits == NULL (the default, all shipped configs) = no mask.  Strides in words per batch element.               */
 typedef struct {
   const void* q; int ldq; long long strideQ; int nq;
   const void* k0; int ldk0; long long strideK0; const void* vt0; int ldv0; long long strideV0; int n0;
@@ -111,6 +115,9 @@ typedef struct {
   int B, H, d;
   float scale;      /* d^-0.5 */
   int dtype;
+  const void* qbits; long long strideQb;             /* [B][nq] u32, or NULL */
+  const void* kbits0; long long strideKb0;           /* [B][n0] u32 */
+  const void* kbits1; long long strideKb1;           /* [B][n1] u32 (when n1 > 0) */
 } idf_attn_args;
 int idf_attention(const idf_attn_args* a, void* stream);
 

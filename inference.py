@@ -1,19 +1,18 @@
 #!/usr/bin/env python
-"""Entry-point mirror of the reference ``inference.py`` (demo CLI) for the MI355X sampling path.
+"""Entry-point mirror of the reference ``inference.py`` (demo CLI) on the MI355X path.
 
-Same flags and the same demo-JSON format (``demos/*.json``: caption, width/height, annos[{bbox, mask, point, scribble,
-caption}]) as the reference (inference.py:165-297).  What is in scope here is the SAMPLING path: UNet denoise step +
-PLMS / Multi-instance Sampler on the HIP engine.  The two neighbours of the path that need assets which do not exist
-offline are handled explicitly, never silently:
+Same flags, same demo-JSON format (``demos/*.json``: caption, width/height, annos[{bbox, mask, point, scribble,
+caption}]) and the same call sequence as the reference (inference.py:165-309): demo JSON -> ``meta`` ->
+``utils.input.prepare_batch`` (+ ``prepare_instance_meta`` per instance when MIS is on) -> ``PLMSSampler`` /
+``PLMSSamplerInst`` -> ``autoencoder.decode`` -> PNGs.  UNet, samplers and VAE decoder run on the HIP engine.
 
-  * text encoding (CLIP-L/14, `ldm/modules/encoders`, `utils/model.py:12-18`): ``--text_encoder synthetic`` (default)
-    draws a deterministic embedding per string (seeded by its hash) -- layout-faithful, not semantically meaningful;
-    ``--text_encoder clip --clip_path DIR`` uses a local HF CLIP checkpoint when one is available.
-  * VAE decode (`ldm/models/autoencoder.py`, out of scope): the final LATENTS are saved as
-    ``<output>/<name>/latents.pt``; decode them with the reference autoencoder.
-
-Weights: ``--ckpt instancediffusion_sd15.pth`` loads the reference checkpoint (``['ema']`` else ``['model']``,
-utils/checkpoint.py:238-244); without it ``--synthetic_weights`` must be given (seeded random weights).
+Two neighbours of the path need assets that do not exist offline; both are handled explicitly, never silently:
+  * text encoding (CLIP-L/14: ``ldm/modules/encoders``, ``utils/model.py:12-18``): with ``--ckpt`` the checkpoint's
+    text encoder is used (needs the BPE vocabulary locally, see host/text_encoder.py); ``--text_encoder synthetic``
+    (default without a checkpoint) draws a deterministic embedding per string -- layout-faithful, not meaningful;
+  * weights: ``--ckpt instancediffusion_sd15.pth`` goes through ``utils.checkpoint.load_model_ckpt`` (ema -> model
+    fallback, autoencoder / text_encoder / diffusion sub-dicts); without it ``--synthetic_weights`` must be given.
+The SDXL-refiner cascade (``--cascade_strength``, diffusers + downloads) is outside the path.
 """
 from __future__ import annotations
 
@@ -27,10 +26,10 @@ import torch
 
 from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
 from instancediffusion_amd.host.config import instantiate_from_config, load_yaml
+from instancediffusion_amd.host.input import meta_from_demo_json, prepare_batch, prepare_instance_meta
 from instancediffusion_amd.host.samplers import PLMSSampler, PLMSSamplerInst
 
 MAX_OBJS = 30
-N_SCRIBBLE, N_POLYGON = 20, 256
 
 
 def text_embedding(s: str, dim: int = 768, rows: int = 1) -> torch.Tensor:
@@ -39,7 +38,8 @@ def text_embedding(s: str, dim: int = 768, rows: int = 1) -> torch.Tensor:
 
 
 class SyntheticTextEncoder:
-    """Stand-in for FrozenCLIPEmbedder.encode (encoders/modules.py:144-172): [B, 77, 768] per prompt, deterministic."""
+    """Stand-in for FrozenCLIPEmbedder.encode (encoders/modules.py:144-172) and for the pooled CLIP phrase feature
+    (utils/model.py:130-152): deterministic per string."""
 
     def encode(self, prompts):
         return torch.stack([text_embedding("ctx:" + p, 768, 77) for p in prompts])
@@ -48,42 +48,44 @@ class SyntheticTextEncoder:
         return text_embedding("pooled:" + phrase, 768, 1)[0]
 
 
-def rescale_box(bbox, width, height):
-    """xywh pixels -> normalised xyxy (inference.py:132-137)."""
-    x0, y0 = bbox[0] / width, bbox[1] / height
-    x1, y1 = (bbox[0] + bbox[2]) / width, (bbox[1] + bbox[3]) / height
-    return [x0, y0, x1, y1]
+class ClipPhraseEncoder:
+    """Pooled phrase features from the checkpoint's own CLIP text transformer (the reference loads a second copy of
+    the same CLIP-L/14 text model through ``CLIPModel``; its pooler output is the same tensor)."""
+
+    def __init__(self, text_encoder):
+        self.text_encoder = text_encoder
+
+    def pooled(self, phrase):
+        return self.text_encoder.encode([phrase], return_pooler_output=True)[1][0]
 
 
-def build_batch(data: dict, enc: SyntheticTextEncoder, batch: int) -> dict:
-    """`prepare_batch` (utils/input.py:41-125) for the fields the tokenizer consumes; masks/polygons stay zero exactly
-    as the reference demo script leaves them (inference.py:249 re-initialises the mask list)."""
-    W, H = data.get("width", 512), data.get("height", 512)
-    out = dict(boxes=torch.zeros(MAX_OBJS, 4), masks=torch.zeros(MAX_OBJS), text_embeddings=torch.zeros(MAX_OBJS, 768),
-               points=torch.zeros(MAX_OBJS, 2), scribbles=torch.zeros(MAX_OBJS, N_SCRIBBLE * 2),
-               polygons=torch.zeros(MAX_OBJS, N_POLYGON * 2), segs=torch.zeros(MAX_OBJS, 512, 512))
-    phrases = []
-    for i, a in enumerate(data["annos"][:MAX_OBJS]):
-        box = rescale_box(a["bbox"], W, H)
-        out["boxes"][i] = torch.tensor(box)
-        out["masks"][i] = 1
-        out["text_embeddings"][i] = enc.pooled(a["caption"])
-        pt = a.get("point")
-        out["points"][i] = torch.tensor([pt[0] / W, pt[1] / H]) if pt else torch.tensor(
-            [(box[0] + box[2]) / 2, (box[1] + box[3]) / 2])
-        sc = a.get("scribble")
-        if sc:
-            flat = torch.tensor([[p[0] / W, p[1] / H] for p in sc][:N_SCRIBBLE]).flatten()
-            out["scribbles"][i, :flat.numel()] = flat
-        phrases.append(a["caption"])
-    return {k: v.unsqueeze(0).repeat(batch, *([1] * v.dim())) for k, v in out.items()}, phrases
+def get_model_inputs(meta, gi, text_encoder, phrase_encoder, num_images, device, starting_noise, negative_prompt=None,
+                     instance_input=False):
+    """inference.py:39-78."""
+    batch = prepare_batch(meta, batch=num_images, max_objs=MAX_OBJS, model=phrase_encoder, processor=None,
+                          image_size=starting_noise.shape[-1], use_masked_att=False, device=device)
+    context = text_encoder.encode([meta["prompt"]] * num_images).to(device)
+    uc = None
+    if not instance_input:
+        uc = text_encoder.encode(num_images * [negative_prompt if negative_prompt is not None else ""]).to(device)
+    grounding_input = gi.prepare(batch)
+    return dict(x=starting_noise, timesteps=None, context=context, grounding_input=grounding_input), uc
 
 
-def instance_batch(full: dict, i: int) -> dict:
-    out = {k: torch.zeros_like(v) for k, v in full.items()}
-    for k in full:
-        out[k][:, 0] = full[k][:, i]
-    return out
+def save_images(images: torch.Tensor, folder: str) -> list:
+    """inference.py:120-130: clamp to [-1, 1], map to uint8 RGB, one PNG per sample (numbered after existing files)."""
+    import numpy as np
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    start = len(os.listdir(folder))
+    names = []
+    for i, sample in enumerate(images):
+        sample = torch.clamp(sample, min=-1, max=1) * 0.5 + 0.5
+        arr = (sample.float().cpu().numpy().transpose(1, 2, 0) * 255).astype(np.uint8)
+        name = os.path.join(folder, f"{start + i}.png")
+        Image.fromarray(arr).save(name)
+        names.append(name)
+    return names
 
 
 def main():
@@ -93,71 +95,82 @@ def main():
     ap.add_argument("--guidance_scale", type=float, default=7.5)
     ap.add_argument("--negative_prompt", type=str, default="longbody, lowres, bad anatomy, bad hands, missing fingers, "
                     "extra digit, fewer digits, cropped, worst quality, low quality")
-    ap.add_argument("--input_json", type=str, required=True)
+    ap.add_argument("--input_json", type=str, default="demos/demo_four_boxes.json")
     ap.add_argument("--ckpt", type=str, default=None)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--alpha", type=float, default=0.8)
-    ap.add_argument("--mis", type=float, default=0.4)
+    ap.add_argument("--alpha", type=float, default=0.75)
+    ap.add_argument("--mis", type=float, default=0.36)
     ap.add_argument("--cascade_strength", type=float, default=0.0)
-    ap.add_argument("--test_config", type=str, default="configs/test_box.yaml")
+    ap.add_argument("--test_config", type=str, default="configs/test_mask.yaml")
     ap.add_argument("--device", type=str, default="cuda")
-    ap.add_argument("--text_encoder", choices=["synthetic", "clip"], default="synthetic")
-    ap.add_argument("--clip_path", type=str, default=None)
+    ap.add_argument("--text_encoder", choices=["synthetic", "clip"], default=None)
     ap.add_argument("--synthetic_weights", action="store_true")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--save_latents", action="store_true")
     args = ap.parse_args()
     if args.cascade_strength > 0:
         raise SystemExit("the SDXL refiner cascade is outside the sampling path (needs diffusers + downloads)")
-    if args.text_encoder == "clip":
-        raise SystemExit("CLIP text encoding needs local HF weights; wire ldm.modules.encoders from the reference tree")
+    dev = torch.device(args.device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
 
-    cfg = load_yaml(args.test_config)
-    with torch.device("meta"):
-        model = instantiate_from_config(cfg["model"])
     if args.ckpt:
-        saved = torch.load(args.ckpt, map_location="cpu")
-        sd = saved["ema"] if "ema" in saved else saved["model"]
+        from utils.checkpoint import load_model_ckpt
+        model, autoencoder, clip_text, diffusion, cfg = load_model_ckpt(args.ckpt, args, args.device)
+        use_clip = (args.text_encoder or "clip") == "clip"
     elif args.synthetic_weights:
         from instancediffusion_amd import synth
-        sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        cfg = load_yaml(args.test_config)
+        with torch.device("meta"):
+            model = instantiate_from_config(cfg["model"])
+            autoencoder = instantiate_from_config(cfg["autoencoder"])
+        model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}),
+                              assign=True)
         model.first_conv_sd_override = synth.synth_first_conv_sd()
+        autoencoder.load_state_dict(
+            synth.synth_state_dict({k: tuple(v.shape) for k, v in autoencoder.state_dict().items()}, 7), assign=True)
+        model.eval(), autoencoder.eval()
+        diffusion = instantiate_from_config(cfg["diffusion"]).to(args.device)
+        clip_text, use_clip = None, False
+        if args.text_encoder == "clip":
+            raise SystemExit("--text_encoder clip needs --ckpt (the CLIP weights live in the checkpoint)")
     else:
         raise SystemExit("give --ckpt instancediffusion_sd15.pth, or --synthetic_weights for a dry run")
-    model.load_state_dict(sd, assign=True)
-    model.eval()
-    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    diffusion = instantiate_from_config(cfg["diffusion"]).to(args.device)
+    model.compute_dtype = dtype
+    autoencoder.compute_dtype = dtype
     gi = instantiate_from_config(cfg["grounding_tokenizer_input"])
     model.grounding_tokenizer_input = gi
+    text_encoder = clip_text if use_clip else SyntheticTextEncoder()
+    phrase_encoder = ClipPhraseEncoder(clip_text) if use_clip else text_encoder
 
     data = json.load(open(args.input_json))
-    enc = SyntheticTextEncoder()
-    dev = torch.device(args.device)
-    batch, phrases = build_batch(data, enc, args.num_images)
-    batch = {k: v.to(dev) for k, v in batch.items()}
+    save_folder_name = f"gc{args.guidance_scale}-seed{args.seed}-alpha{args.alpha}"
+    meta = meta_from_demo_json(data, args.alpha, ckpt=args.ckpt, save_folder_name=save_folder_name)
     torch.manual_seed(args.seed)
-    noise = torch.randn(args.num_images, 4, model.image_size, model.image_size).to(dev)
-    context = enc.encode([data["caption"]] * args.num_images).to(dev)
-    uc = enc.encode([args.negative_prompt] * args.num_images).to(dev)
-    ag = partial(alpha_generator, type=[args.alpha, 0.0, 1 - args.alpha])
-    inp = dict(x=noise, timesteps=None, context=context, grounding_input=gi.prepare(batch))
+    starting_noise = torch.randn(args.num_images, 4, model.image_size, model.image_size).to(dev)
+
+    inp, uc = get_model_inputs(meta, gi, text_encoder, phrase_encoder, args.num_images, dev, starting_noise,
+                               args.negative_prompt)
+    ag = partial(alpha_generator, type=meta["alpha_type"])
     shape = (args.num_images, model.in_channels, model.image_size, model.image_size)
     if args.mis > 0:
         sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=ag, set_alpha_scale=set_alpha_scale, mis=args.mis)
         inputs = [inp]
-        for i, ph in enumerate(phrases):
-            inputs.append(dict(x=noise, timesteps=None, context=enc.encode([ph] * args.num_images).to(dev),
-                               grounding_input=gi.prepare(instance_batch(batch, i))))
-        gi.prepare(batch)
-        samples = sampler.sample(S=50, shape=shape, input=inputs, uc=uc, guidance_scale=args.guidance_scale)
+        for i in range(len(meta["phrases"])):
+            inst, _ = get_model_inputs(prepare_instance_meta(meta, i), gi, text_encoder, phrase_encoder, args.num_images,
+                                       dev, starting_noise, instance_input=True)
+            inputs.append(inst)
+        samples = sampler.sample(S=args.steps, shape=shape, input=inputs, uc=uc, guidance_scale=args.guidance_scale)
     else:
         sampler = PLMSSampler(diffusion, model, alpha_generator_func=ag, set_alpha_scale=set_alpha_scale)
-        samples = sampler.sample(S=50, shape=shape, input=inp, uc=uc, guidance_scale=args.guidance_scale)
-    name = os.path.splitext(os.path.basename(args.input_json))[0]
-    folder = os.path.join(args.output, name)
-    os.makedirs(folder, exist_ok=True)
-    torch.save(dict(latents=samples.cpu(), caption=data["caption"], phrases=phrases), os.path.join(folder, "latents.pt"))
-    print(f"saved {tuple(samples.shape)} latents to {folder}/latents.pt (decode with the reference AutoencoderKL)")
+        samples = sampler.sample(S=args.steps, shape=shape, input=inp, uc=uc, guidance_scale=args.guidance_scale)
+    images = autoencoder.decode(samples)                                   # inference.py:95
+    folder = os.path.join(args.output, save_folder_name)
+    names = save_images(images, folder)
+    if args.save_latents:
+        torch.save(dict(latents=samples.cpu(), caption=data["caption"], phrases=meta["phrases"]),
+                   os.path.join(folder, "latents.pt"))
+    print(f"saved {len(names)} images {tuple(images.shape[1:])} to {folder}")
 
 
 if __name__ == "__main__":

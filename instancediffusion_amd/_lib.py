@@ -40,7 +40,8 @@ class AttnArgs(C.Structure):
                 ("k0", vp), ("ldk0", ci), ("strideK0", ll), ("vt0", vp), ("ldv0", ci), ("strideV0", ll), ("n0", ci),
                 ("k1", vp), ("ldk1", ci), ("strideK1", ll), ("vt1", vp), ("ldv1", ci), ("strideV1", ll), ("n1", ci),
                 ("out", vp), ("ldo", ci), ("strideO", ll),
-                ("B", ci), ("H", ci), ("d", ci), ("scale", cf), ("dtype", ci)]
+                ("B", ci), ("H", ci), ("d", ci), ("scale", cf), ("dtype", ci),
+                ("qbits", vp), ("strideQb", ll), ("kbits0", vp), ("strideKb0", ll), ("kbits1", vp), ("strideKb1", ll)]
 
 
 # every symbol include/idf.h declares: name -> (restype, argtypes)

@@ -29,7 +29,9 @@ constexpr int VSTR = 72;           // V^T LDS row stride in elements (144 B = 9 
 #ifndef IDF_ATTN_MIN_WAVES
 #define IDF_ATTN_MIN_WAVES 1
 #endif
-template <int DT, int NKS, int NMT, bool MFMASUM>
+// MASK: instance-visibility bit masks (see AttnParams): the tile's 64 key words ride along in LDS; a score whose
+// (query word & key word) is zero -- and which is not the query's own token -- becomes -inf before the softmax.
+template <int DT, int NKS, int NMT, bool MFMASUM, bool MASK = false>
 __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn_kernel(const AttnParams p) {
   constexpr int KSTR = (2 * NKS + 1) * 8;          // K LDS row stride (elements): odd number of 16-B slots
   constexpr int KCH_MAX = (KVT * 2 * NKS + 255) / 256;
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
   constexpr int KSZ = KVT * KSTR, VSZ = NMT * 32 * VSTR;
   __shared__ __attribute__((aligned(16))) unsigned short Kl[2 * KSZ];     // double-buffered: ONE barrier per KV tile
   __shared__ __attribute__((aligned(16))) unsigned short Vl[2 * VSZ];
+  __shared__ __attribute__((aligned(16))) unsigned Bl[MASK ? 2 * KVT : 4];  // key mask words of the two staged tiles
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -68,6 +71,9 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     }
   }
 
+  unsigned qb = 0xffffffffu;
+  if (MASK) qb = p.qbits[(size_t)b * p.sQb + min(qrow, p.nq - 1)];
+
   const int T0 = (p.n[0] + KVT - 1) / KVT;
   const int T1 = (p.n[1] + KVT - 1) / KVT;
   const int T = T0 + T1;
@@ -97,10 +103,12 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
   }
 
   u32x4 kreg[KCH_MAX], vreg[VCH_MAX];
+  unsigned breg = 0u;
   auto prefetch = [&](int t) {
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
+    if (MASK && tid < KVT) breg = p.kbits[seg][(size_t)b * p.sKb[seg] + min(kv0 + tid, n - 1)];
     const int ldk = p.ldk[seg], ldv = p.ldv[seg];
     const unsigned short* kb = p.k[seg] + (size_t)b * p.sK[seg] + h * d;
     const unsigned short* vb = p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * d) * ldv + kv0 + v_ch8;
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
   auto commit = [&](int buf) {
     unsigned short* Kb = Kl + buf * KSZ;
     unsigned short* Vb = Vl + buf * VSZ;
+    if (MASK && tid < KVT) Bl[buf * KVT + tid] = breg;
 #pragma unroll
     for (int i = 0; i < KCH_MAX; ++i)
       if (k_row[i] >= 0) *reinterpret_cast<u32x4*>(Kb + k_lds[i]) = kreg[i];
@@ -194,15 +203,34 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
           s[st][r] = (kv >= nvalid) ? -INFINITY : s[st][r];
         }
     }
+    if (MASK) {
+      const unsigned* bw = Bl + (t & 1) * KVT;
+      const int self_kv = (seg == 0) ? (qrow - kv0) : -1;          // tile-local index of the query's own token
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int kvb = st * 32 + 8 * q4 + 4 * hi;
+          const u32x4 kw = *reinterpret_cast<const u32x4*>(bw + kvb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = ((qb & kw[e]) != 0u) | (kvb + e == self_kv);
+            s[st][4 * q4 + e] = ok ? s[st][4 * q4 + e] : -INFINITY;
+          }
+        }
+    }
     float mx = s[0][0];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);      // c > 0
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+    float m_new = fmaxf(m_run, mx * c);            // c > 0
+    // MASK: every key seen so far may be masked for this query (m_new = -inf): keep exp2 arguments finite
+    const float m_use = (MASK && m_new == -INFINITY) ? 0.0f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);      // first tile: exp2(-inf) = 0
     m_run = m_new;
+    m_new = m_use;
     float rs = 0.0f;
 #pragma unroll
     for (int st = 0; st < 2; ++st)
@@ -277,8 +305,13 @@ int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   const int nks = (p.d + 15) / 16, nmt = (p.d + 31) / 32;
 #define IDF_ATTN_CASE(KS, MT) \
   if (nks == KS && nmt == MT) { \
-    if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false>), grid, block, 0, s, p); \
+    if (p.qbits) { \
+      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true, true>), grid, block, 0, s, p); \
+      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false, true>), grid, block, 0, s, p); \
+    } else { \
+      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true>), grid, block, 0, s, p); \
+      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false>), grid, block, 0, s, p); \
+    } \
     return idf_launch_status(); }
   IDF_ATTN_CASE(1, 1)    // d = 8, 16
   IDF_ATTN_CASE(2, 1)    // d = 24, 32
@@ -321,8 +354,15 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
   p.out = (unsigned short*)a->out; p.ldo = a->ldo; p.sO = a->strideO;
   p.H = a->H; p.d = a->d;
   p.scale_log2 = a->scale * 1.4426950408889634f;
+  if (a->qbits) {                                   // instance-visibility mask: 32-queries-per-wave kernel only
+    if (!a->kbits0 || (a->n1 > 0 && !a->kbits1)) return IDF_E_ARG;
+    if ((((uintptr_t)a->qbits) | ((uintptr_t)a->kbits0) | ((uintptr_t)a->kbits1)) & 3u) return IDF_E_ALIGN;
+    p.qbits = (const unsigned*)a->qbits; p.sQb = a->strideQb;
+    p.kbits[0] = (const unsigned*)a->kbits0; p.sKb[0] = a->strideKb0;
+    p.kbits[1] = (const unsigned*)(a->n1 > 0 ? a->kbits1 : a->kbits0); p.sKb[1] = a->n1 > 0 ? a->strideKb1 : a->strideKb0;
+  }
   hipStream_t s = (hipStream_t)stream;
-  if (idf_attn2_mode() > 0) {
+  if (!a->qbits && idf_attn2_mode() > 0) {
     const int rc = idf_launch_attn2(p, a->B, a->dtype, s);
     if (rc != IDF_ATTN2_UNSUPPORTED) return rc;
   }

@@ -11,6 +11,10 @@ struct AttnParams {
   unsigned short* out; int ldo; long long sO;
   int H, d;
   float scale_log2;   // d^-0.5 * log2(e)
+  // optional instance-visibility mask (masked gated self-attention, reference attention.py:187-255): query q may attend
+  // key j iff (qbits[q] & kbits[seg][j]) != 0, or j is q's own token in segment 0.  NULL qbits = no mask.
+  const unsigned* qbits; long long sQb;
+  const unsigned* kbits[2]; long long sKb[2];
 };
 
 }  // namespace idfattn

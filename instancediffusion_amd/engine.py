@@ -382,18 +382,21 @@ class UNetEngine:
             ops.gemm(h1.view(B, N, -1), l2.w, objs[:, i * N:(i + 1) * N, :], bias=l2.b)
         # --- segmentation tokens (text_grounding_net.py:226-231, 279-285)
         segs = g["segs"]
-        use_segs = (not drop_segs) and bool((segs.reshape(B, -1).sum(1) > 0).any())
+        if segs.dim() == 4 and segs.shape[0] > 1 and segs.stride(0) == 0:
+            segs = segs[:1]               # batch-broadcast mask stack (host/input.py): tokenize it once, exact hoist
+        Bs = segs.shape[0]
+        use_segs = (not drop_segs) and bool((segs.reshape(Bs, -1).sum(1) > 0).any())
         l0, l1, l2 = self.tok_mlps[4]
         null_in = self.tok_null["seg"].view(1, 1, -1) + self.tok_pos                         # [1, 64, 3072]
         if use_segs:
             segs_r = segs.to(dev, torch.float32)
             if segs_r.shape[-1] != pn.resize_input:                                          # :227 nearest resize
                 segs_r = torch.nn.functional.interpolate(segs_r, pn.resize_input, mode="nearest")
-            feat = self.convnext_features(segs_r)                                            # [B, 16, 16, 768]
-            sf = feat.reshape(B, -1).float()[:, self.seg_gather.reshape(-1)].reshape(B, 64, -1)   # :230-231 layout
-            sm = (segs_r.reshape(B, -1).sum(1) > 0).float().view(B, 1, 1)                    # :279
+            feat = self.convnext_features(segs_r)                                            # [Bs, 16, 16, 768]
+            sf = feat.reshape(Bs, -1).float()[:, self.seg_gather.reshape(-1)].reshape(Bs, 64, -1)  # :230-231 layout
+            sm = (segs_r.reshape(Bs, -1).sum(1) > 0).float().view(Bs, 1, 1)                  # :279
             seg_in = sf * sm + (1 - sm) * self.tok_null["seg"].view(1, 1, -1) + self.tok_pos  # :282-285
-            rows = B * 64
+            rows = Bs * 64
         else:
             seg_in, rows = null_in, 64                                                       # batch-independent
         seg_in = seg_in.reshape(rows, -1).contiguous()

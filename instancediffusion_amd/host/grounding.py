@@ -52,7 +52,8 @@ class GroundingNetInput:
             "boxes": z(b, self.max_box, 4), "masks": z(b, self.max_box),
             "positive_embeddings": z(b, self.max_box, self.in_dim),
             "scribbles": z(b, self.max_box, self.dim_scribbles), "polygons": z(b, self.max_box, self.dim_polygons),
-            "segs": z(b, self.max_box, self.dim_segs, self.dim_segs), "points": z(b, self.max_box, 2),
+            # 31 MB per sample at 512^2: one zero plane set, broadcast over the batch (stride-0 view, read-only use)
+            "segs": z(1, self.max_box, self.dim_segs, self.dim_segs).expand(b, -1, -1, -1), "points": z(b, self.max_box, 2),
         }
         if self.return_att_masks:
             out["att_masks"] = z(b, self.max_box, self.image_size, self.image_size)

@@ -151,8 +151,12 @@ class HipOps:
                                         self._stream()), "idf_conv_in")
         return out
 
-    def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0):
-        """q [B,Nq,C] view, k [B,n,C] view, vt [B,C,ld>=ceil64(n)], out [B,Nq,C] view."""
+    def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0, qbits=None, kbits0=None, kbits1=None):
+        """q [B,Nq,C] view, k [B,n,C] view, vt [B,C,ld>=ceil64(n)], out [B,Nq,C] view.  Optional visibility mask:
+        int32 words qbits [B,Nq], kbits0 [B,>=n0], kbits1 [B,>=n1] (see include/idf.h)."""
+        if qbits is not None:
+            for t in (qbits, kbits0) + ((kbits1,) if n1 else ()):
+                assert t.dtype == torch.int32 and t.stride(-1) == 1 and t.dim() == 2
         B, Nq, Cc = q.shape
         d = Cc // heads
         a = _lib.AttnArgs(
@@ -164,7 +168,11 @@ class HipOps:
             vt1=None if vt1 is None else vt1.data_ptr(), ldv1=0 if vt1 is None else vt1.stride(1),
             strideV1=0 if vt1 is None else vt1.stride(0), n1=n1,
             out=out.data_ptr(), ldo=out.stride(1), strideO=out.stride(0),
-            B=B, H=heads, d=d, scale=float(d) ** -0.5, dtype=self.dt)
+            B=B, H=heads, d=d, scale=float(d) ** -0.5, dtype=self.dt,
+            qbits=None if qbits is None else qbits.data_ptr(), strideQb=0 if qbits is None else qbits.stride(0),
+            kbits0=None if qbits is None else kbits0.data_ptr(), strideKb0=0 if qbits is None else kbits0.stride(0),
+            kbits1=None if (qbits is None or not n1) else kbits1.data_ptr(),
+            strideKb1=0 if (qbits is None or not n1) else kbits1.stride(0))
         _lib.check(self.lib.idf_attention(C.byref(a), self._stream()), "idf_attention")
         return out
 

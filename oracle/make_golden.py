@@ -235,6 +235,81 @@ def gen_vae_case(tag: str, variant: str, latent: int, batch: int):
     return schema
 
 
+def gen_input_case():
+    """``prepare_batch`` / ``prepare_instance_meta`` of the UNMODIFIED reference ``utils/input.py`` (imported with stub
+    modules for its un-installable imports: pycocotools, dataset.*, and ``utils.model.get_clip_feature`` replaced by a
+    deterministic hash embedding -- the same stand-in the mirror's test uses).  Large tensors are stored as digests."""
+    import hashlib
+    import importlib
+
+    def text_embedding(s, dim=768, rows=1):
+        g = torch.Generator().manual_seed(int.from_bytes(hashlib.sha256(s.encode()).digest()[:7], "little"))
+        return torch.randn(rows, dim, generator=g)
+
+    def batch_to_device(batch, device):
+        return batch
+    stubs = {"pycocotools": types.ModuleType("pycocotools"), "pycocotools.mask": types.ModuleType("pycocotools.mask"),
+             "dataset": types.ModuleType("dataset"), "dataset.jsondataset": types.ModuleType("dataset.jsondataset"),
+             "dataset.decode_item": types.ModuleType("dataset.decode_item"), "utils": types.ModuleType("utils"),
+             "utils.model": types.ModuleType("utils.model")}
+    stubs["pycocotools"].mask = stubs["pycocotools.mask"]
+    stubs["dataset.jsondataset"].batch_to_device = batch_to_device
+    stubs["dataset.decode_item"].sample_random_points_from_mask = None
+    stubs["dataset.decode_item"].sample_sparse_points_from_mask = None
+    stubs["utils"].__path__ = [os.path.join(REF, "utils")]
+    stubs["utils.model"].get_clip_feature = lambda model, processor, phrase, is_image=False: (
+        None if phrase is None else text_embedding("pooled:" + phrase))
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        ref_input = importlib.import_module("utils.input")
+        data = json.load(open(os.path.join(REF, "demos", "demo_cat_dog_robin.json")))
+        W, H = data["width"], data["height"]
+        locations = [[b[0] / W, b[1] / H, (b[0] + b[2]) / W, (b[1] + b[3]) / H] for b in (a["bbox"] for a in data["annos"])]
+        n = len(locations)
+        segs = np.zeros((n, 512, 512), dtype=np.float32)
+        for i, l in enumerate(locations[:2]):                      # two box-filled instance masks, two empty
+            segs[i, int(l[1] * 512):int(l[3] * 512), int(l[0] * 512):int(l[2] * 512)] = 1
+        rng = np.random.RandomState(5)
+        meta = dict(ckpt=None, prompt=data["caption"], phrases=[a["caption"] for a in data["annos"]],
+                    polygons=[list(rng.rand(512).astype(np.float32)) for _ in range(n)],
+                    scribbles=[list(rng.rand(40).astype(np.float32)) for _ in range(n)], segs=segs, locations=locations,
+                    points=[[(l[0] + l[2]) / 2, (l[1] + l[3]) / 2] for l in locations], alpha_type=[0.8, 0.0, 0.2],
+                    save_folder_name="x", text_mask=[1, 0, 1, 1])
+        meta["instance_meta"] = [ref_input.prepare_instance_meta(meta, i) for i in range(n)]
+        out = ref_input.prepare_batch(meta, batch=2, max_objs=30, model=None, processor=None, image_size=64,
+                                      use_masked_att=True, device="cpu")
+
+        def digest(d):
+            r = {}
+            for k, v in d.items():
+                if not torch.is_tensor(v):
+                    continue
+                if v.numel() > 200000:
+                    r[k] = dict(shape=list(v.shape), sums=v.reshape(v.shape[0], v.shape[1], -1).sum(-1).clone(),
+                                pooled=torch.nn.functional.avg_pool2d(v[:1, :4], v.shape[-1] // 16).clone())
+                else:                                              # batch rows are copies; slots >= 6 are zero padding
+                    assert bool((v == v[:1]).all())
+                    r[k] = dict(shape=list(v.shape), head=v[0, :6].clone(), rest_abs_sum=float(v[0, 6:].abs().sum()))
+            return r
+        gold = dict(meta=dict(n=n, text_mask=[1, 0, 1, 1], seed=5, phrases=list(meta["phrases"]), locations=locations),
+                    main=digest(out),
+                    inst=[digest(d) for d in out["instance_meta"]],
+                    instance_meta_keys=sorted(meta["instance_meta"][0].keys()),
+                    complete_mask=[ref_input.complete_mask(None, 5), ref_input.complete_mask(0.5, 5),
+                                   ref_input.complete_mask([0, 1], 5)],
+                    convert_points=ref_input.convert_points([100.0, 600.0, 800.0, 20.0], dict(width=768, height=512)))
+        torch.save(gold, os.path.join(GOLD, "prepare_batch.pt"))
+        print("[golden] prepare_batch:", {k: v["shape"] for k, v in gold["main"].items()})
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.modules.pop("utils.input", None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -259,6 +334,8 @@ def main():
         gen_vae_case("vae_tiny", "tiny", 8, 2)
         schema = gen_vae_case("vae_full_16", "full", 16, 1)
         json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "vae_schema.json"), "w"))
+    if args.only in ("all", "input"):
+        gen_input_case()
     print("done")
 
 

@@ -74,16 +74,28 @@ def test_reference_yaml_instantiates(name):
 
 
 def test_inference_cli_input_builder():
-    """inference.py parses the reference's demo-JSON format into prepare_batch-shaped tensors."""
+    """inference.py parses the reference's demo-JSON format and builds prepare_batch tensors through the mirrors."""
     import json
     import torch
     import inference
     from instancediffusion_amd import synth
+    from instancediffusion_amd.host.input import meta_from_demo_json, prepare_instance_meta
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
     data = json.load(open(os.path.join(REPO, "demos", "demo_four_boxes.json")))
-    batch, phrases = inference.build_batch(data, inference.SyntheticTextEncoder(), batch=2)
-    assert batch["boxes"].shape == (2, 30, 4) and batch["segs"].shape == (2, 30, 512, 512)
-    assert torch.allclose(batch["boxes"][0, :4], torch.tensor(synth.C1_BOXES), atol=2e-3)
-    assert batch["masks"][0].sum() == 4 and len(phrases) == 4
-    assert torch.allclose(batch["points"][0, 0], (batch["boxes"][0, 0, :2] + batch["boxes"][0, 0, 2:]) / 2)
-    inst = inference.instance_batch(batch, 2)
-    assert torch.equal(inst["boxes"][:, 0], batch["boxes"][:, 2]) and inst["masks"].sum() == 2
+    meta = meta_from_demo_json(data, 0.75)
+    enc = inference.SyntheticTextEncoder()
+    gi = GroundingNetInput()
+    noise = torch.zeros(2, 4, 64, 64)
+    inp, uc = inference.get_model_inputs(meta, gi, enc, enc, 2, "cpu", noise, "bad")
+    g = inp["grounding_input"]
+    assert g["boxes"].shape == (2, 30, 4) and g["segs"].shape == (2, 30, 512, 512) and uc.shape == (2, 77, 768)
+    assert torch.allclose(g["boxes"][0, :4], torch.tensor(synth.C1_BOXES), atol=2e-3)
+    assert g["masks"][0].sum() == 4 and inp["context"].shape == (2, 77, 768)
+    assert torch.allclose(g["points"][0, 0], (g["boxes"][0, 0, :2] + g["boxes"][0, 0, 2:]) / 2)
+    assert torch.equal(g["positive_embeddings"][0, 1], enc.pooled(data["annos"][1]["caption"]))
+    inst, uc_i = inference.get_model_inputs(prepare_instance_meta(meta, 2), gi, enc, enc, 2, "cpu", noise,
+                                            instance_input=True)
+    gi2 = inst["grounding_input"]
+    assert uc_i is None and torch.equal(gi2["boxes"][:, 0], g["boxes"][:, 2]) and gi2["masks"].sum() == 2
+    null = gi.get_null_input()
+    assert null["segs"].shape == (2, 30, 512, 512) and null["segs"].stride(0) == 0

@@ -96,3 +96,26 @@ def test_model_forward_refuses_without_hip(monkeypatch):
     model = build_model(cfg)
     with pytest.raises(RuntimeError):
         model.engine
+
+
+def test_broadcast_mask_stack_is_tokenized_once():
+    """utils/input.py mirror hands ``segs`` over as a stride-0 batch broadcast; the tokenizer must give the same tokens
+    as for the reference's ``.repeat`` copies while running the ConvNeXt backbone on ONE sample."""
+    gold = cases.load_golden("tiny_mask")
+    meta = gold["meta"]
+    cfg = cases.cfg_for(meta["cfg"], meta["variant"])
+    inp = cases.build_inputs(dict(meta, batch=1))
+    model = build_model(cfg)
+    gi = GroundingNetInput()
+    gb1 = inp["gb"]
+    rep = {k: v.repeat(3, *([1] * (v.dim() - 1))) for k, v in gb1.items()}
+    bc = dict(rep, segs=gb1["segs"][0].unsqueeze(0).expand(3, *gb1["segs"].shape[1:]))
+    assert bc["segs"].stride(0) == 0
+    with torch.no_grad():
+        e1 = UNetEngine(model, ops=EmulOps(torch.float32), use_graphs=False)
+        t_rep = e1.tokens(gi.prepare(rep))
+        e2 = UNetEngine(model, ops=EmulOps(torch.float32), use_graphs=False)
+        t_bc = e2.tokens(gi.prepare(bc))
+    assert torch.allclose(t_rep, t_bc, atol=1e-6) and t_bc.shape[0] == 3
+    assert e1.ops.calls["seg_in_conv"] == 1 and e2.ops.calls["seg_in_conv"] == 1
+    assert e2.ops.calls["dwconv7x7"] == e1.ops.calls["dwconv7x7"]        # same launches, one third of the rows

@@ -22,6 +22,7 @@ from .host.attention import SpatialTransformer
 from .host.unet import Downsample, ResBlock, UNetModel, Upsample
 
 OBJ_TOKENS = 184
+MASK_RES = 64                  # the reference applies the fuser mask only when H*W == 64*64 (attention.py:195)
 
 
 def _round_up(x: int, m: int) -> int:
@@ -67,25 +68,27 @@ class Cond:
         self.k_obj: List[torch.Tensor] = []                  # per ST layer [B, 184, C]
         self.vt_obj: List[torch.Tensor] = []                 # per ST layer [B, C, 192]
         self.n_ctx = 0
+        # masked gated self-attention only (model built with efficient_attention=False): visibility words, int32
+        self.vis: List[torch.Tensor] = []                    # [] or [qbits [B,4096], kbits0 [B,4096], kbits1 [B,192]]
 
     @staticmethod
     def cat(conds: Sequence["Cond"]) -> "Cond":
         out = Cond(sum(c.B for c in conds))
         out.n_ctx = conds[0].n_ctx
         out.objs = torch.cat([c.objs for c in conds], 0)
-        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj"):
+        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj", "vis"):
             lists = [getattr(c, name) for c in conds]
             setattr(out, name, [torch.cat(ts, 0) for ts in zip(*lists)])
         return out
 
     def _tensors(self):
-        return [self.objs] + self.k_ctx + self.vt_ctx + self.k_obj + self.vt_obj
+        return [self.objs] + self.k_ctx + self.vt_ctx + self.k_obj + self.vt_obj + self.vis
 
     def clone(self) -> "Cond":
         out = Cond(self.B)
         out.n_ctx = self.n_ctx
         out.objs = self.objs.clone()
-        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj"):
+        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj", "vis"):
             setattr(out, name, [t.clone() for t in getattr(self, name)])
         return out
 
@@ -101,7 +104,7 @@ class Cond:
         out = Cond(int(idx.numel()))
         out.n_ctx = self.n_ctx
         out.objs = self.objs[idx].contiguous()
-        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj"):
+        for name in ("k_ctx", "vt_ctx", "k_obj", "vt_obj", "vis"):
             setattr(out, name, [t[idx].contiguous() for t in getattr(self, name)])
         return out
 
@@ -116,6 +119,7 @@ class UNetEngine:
         self.device = ops.device
         self.model = model
         self.heads = model.num_heads
+        self.masked_fuser = not getattr(model, "efficient_attention", True)     # attention.py:189
         self.use_graphs = use_graphs and self.device.type == "cuda"
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
@@ -419,6 +423,21 @@ class UNetEngine:
         c = Cond(B)
         c.n_ctx = n_ctx
         c.objs = self.tokens(grounding)
+        if self.masked_fuser:
+            # attention.py:187-255: instance-visibility mask of the fuser attention, as membership words.  A grounding
+            # input without att_masks, with boxes dropped (eval-mode drop_box_mask) or all-zero masks is unmasked.
+            from .host.attention import visibility_words
+            am = grounding.get("att_masks")
+            if am is None or self.pn.eval_drops()[1]:
+                am = torch.zeros(B, 1, MASK_RES, MASK_RES, device=self.device)
+            assert am.shape[-2:] == (MASK_RES, MASK_RES), "the reference masks at the 64x64 resolution only"
+            am = am.to(self.device)
+            if am.shape[0] != B:
+                am = am.expand(B, *am.shape[1:])
+            n_objs = (OBJ_TOKENS - 64) // 4
+            if am.shape[1] < n_objs:
+                am = torch.cat([am, torch.zeros(B, n_objs - am.shape[1], MASK_RES, MASK_RES, device=self.device)], 1)
+            c.vis = list(visibility_words(am))
         ctx16 = ops.cast16(context.to(self.device, torch.float32).contiguous(), ops.empty((B, n_ctx, cd)))
         ld_ctx, ld_obj = _round_up(n_ctx, 64), _round_up(OBJ_TOKENS, 64)
         for p in self._st_layers():
@@ -456,8 +475,9 @@ class UNetEngine:
             xs = x
         return ops.conv3x3(g2, p["conv2"].w, self.buf(out_role, (B, H, W, Cout)), bias=p["conv2"].b, res=xs)
 
-    def _self_attn(self, a, x2, ln, B, N, C, kv_extra=None):
-        """x2 [B*N, C] residual stream, ln = LayerNorm(x2).  Returns the attention output [B, N, C] (pre out-proj)."""
+    def _self_attn(self, a, x2, ln, B, N, C, kv_extra=None, vis=None):
+        """x2 [B*N, C] residual stream, ln = LayerNorm(x2).  Returns the attention output [B, N, C] (pre out-proj).
+        ``vis``: (qbits, kbits0, kbits1) visibility words of the masked gated self-attention, or None."""
         ops = self.ops
         qk = ops.gemm(ln, a["wqk"], self.buf("st.qk", (B * N, 2 * C))).view(B, N, 2 * C)
         ldv = _round_up(N, 64)
@@ -466,9 +486,12 @@ class UNetEngine:
         att = self.buf("st.att", (B, N, C))
         if kv_extra is None:
             ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads)
-        else:
+        elif vis is None:
             ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads, k1=kv_extra[0], vt1=kv_extra[1],
                           n1=OBJ_TOKENS)
+        else:
+            ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads, k1=kv_extra[0], vt1=kv_extra[1],
+                          n1=OBJ_TOKENS, qbits=vis[0], kbits0=vis[1], kbits1=vis[2])
         return att
 
     def _ff(self, f, x2, ln, M, C, gate=None):
@@ -491,7 +514,8 @@ class UNetEngine:
         if fuser_on:
             i = p["idx"]
             ln = ops.layernorm(y, lnb, *p["f_n1"])
-            att = self._self_attn(p["f_attn"], y, ln, B, N, C, kv_extra=(cond.k_obj[i], cond.vt_obj[i]))
+            vis = cond.vis if (cond.vis and N == MASK_RES * MASK_RES) else None
+            att = self._self_attn(p["f_attn"], y, ln, B, N, C, kv_extra=(cond.k_obj[i], cond.vt_obj[i]), vis=vis)
             ops.gemm(att.view(M, C), p["f_attn"]["out"].w, y, bias=p["f_attn"]["out"].b, res=y, gate=self.gates[i, 0:1])
             ln = ops.layernorm(y, lnb, *p["f_n2"])
             self._ff(p["f_ff"], y, ln, M, C, gate=self.gates[i, 1:2])

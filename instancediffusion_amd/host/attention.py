@@ -99,3 +99,42 @@ class SpatialTransformer(nn.Module):
             [BasicTransformerBlock(qd, key_dim, value_dim, n_heads, d_head, fuser_type,
                                    use_checkpoint=use_checkpoint, efficient_attention=efficient_attention)])
         self.proj_out = Conv(qd, in_channels, 1, zero=True)
+
+
+# ---- masked gated self-attention (attention.py:187-255), SURVEY.md §8 row f-4 ------------------------------------
+ALWAYS = -2 ** 31            # bit 31 as an int32: set in every query word and in every unconditionally visible key
+
+
+def visibility_words(att_masks: torch.Tensor, n_groups: int = 4, n_seg_tokens: int = 64):
+    """The reference's dense [B, 1, N, N] visibility mask of the fuser attention, as 32-bit membership words.
+
+    ``att_masks`` [B, n_objs <= 30, h, w] (binary; ``utils/input.py:34-37``).  Visual token i carries one bit per
+    instance whose box contains it.  Returns int32 tensors
+        qbits  [B, h*w]    instance bits | bit 31,
+        kbits0 [B, h*w]    instance bits                       (visual keys),
+        kbits1 [B, ceil64(4 n_objs + 64)]  per grounding token: box token o -> bit o, point / scribble tokens -> all
+                           ones, mask token o -> bit o, the 64 seg tokens -> all ones (padding -> all ones),
+    such that query q sees key k iff ``(qbits[q] & kbits[k]) != 0`` or k is q itself -- exactly ``mask > 0`` of
+    attention.py:206-253 for the visual query rows (the only rows attention.py:308 keeps).  A sample whose mask stack is
+    all zero is unmasked in the reference (:200): all its words are all-ones."""
+    B, n_objs = att_masks.shape[0], att_masks.shape[1]
+    assert n_objs <= 31, "one bit per instance, bit 31 reserved"
+    dev = att_masks.device
+    m = (att_masks.reshape(B, n_objs, -1) > 0)
+    weights = (torch.ones(n_objs, dtype=torch.int64, device=dev) << torch.arange(n_objs, device=dev)).view(1, n_objs, 1)
+    inst = (m.to(torch.int64) * weights).sum(1)                                        # [B, hw], < 2^31
+    unmasked = ~m.reshape(B, -1).any(1)                                                # [B]
+    full = torch.full_like(inst, 0xFFFFFFFF)
+    q64 = torch.where(unmasked[:, None], full, inst | 0x80000000)
+    k64 = torch.where(unmasked[:, None], full, inst)
+    n1 = n_groups * n_objs + n_seg_tokens
+    ld1 = (n1 + 63) // 64 * 64
+    k1 = torch.full((B, ld1), 0xFFFFFFFF, dtype=torch.int64, device=dev)
+    obj_bits = (torch.ones(n_objs, dtype=torch.int64, device=dev) << torch.arange(n_objs, device=dev))
+    k1[:, :n_objs] = obj_bits                                                          # box tokens
+    k1[:, (n_groups - 1) * n_objs:n_groups * n_objs] = obj_bits                        # mask (polygon) tokens
+    k1 = torch.where(unmasked[:, None], torch.full_like(k1, 0xFFFFFFFF), k1)
+
+    def i32(t):                                                                        # two's-complement reinterpretation
+        return torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32).contiguous()
+    return i32(q64), i32(k64), i32(k1)

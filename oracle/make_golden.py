@@ -310,6 +310,40 @@ def gen_input_case():
         sys.modules.pop("utils.input", None)
 
 
+@torch.no_grad()
+def gen_masked_case(tag="tiny_masked_att"):
+    """Masked gated self-attention (attention.py:187-255): the UNMODIFIED reference UNet built with
+    ``efficient_attention=False`` and fed ``grounding_input['att_masks']`` (utils/input.py:34-37 layout), tiny width,
+    64x64 latent (the only resolution at which the reference applies the mask)."""
+    print(f"[golden] {tag}", flush=True)
+    cfg = load_cfg("test_box.yaml", "tiny")
+    cfg["model"]["params"]["efficient_attention"] = False
+    model, gi, diffusion, schema, synth = build(cfg)
+    g = torch.Generator().manual_seed(1234)
+    bx = synth.random_boxes(3, g)
+    gb = synth.make_grounding_batch(1, bx, g)
+    att = torch.zeros(30, 64, 64)
+    for i in range(3):                                                   # utils/input.py:34-37 (x on dim 0, y on dim 1)
+        b = bx[i].tolist()
+        x1, y1, x2, y2 = (int(np.round(b[0] * 64)), int(np.round(b[1] * 64)), int(np.round(b[2] * 64)), int(np.round(b[3] * 64)))
+        att[i][x1:x2, y1:y2] = 1
+    gb["att_masks"] = att.unsqueeze(0)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    context = torch.randn(1, 77, 768, generator=g)
+    t = torch.full((1,), 981, dtype=torch.long)
+    grounding = gi.prepare(gb, return_att_masks=True)
+    eps_m = model(dict(x=x, timesteps=t, context=context, grounding_input=grounding)).clone()
+    plain = {k: v for k, v in grounding.items() if k != "att_masks"}
+    eps_u = model(dict(x=x, timesteps=t, context=context, grounding_input=plain)).clone()
+    null = gi.get_null_input()
+    assert "att_masks" in null and float(null["att_masks"].sum()) == 0
+    eps_n = model(dict(x=x, timesteps=t, context=context, grounding_input=null)).clone()
+    out = dict(meta=dict(tag=tag, cfg="test_box.yaml", variant="tiny", latent=64, n_boxes=3, batch=1, x_fp=fp(x)),
+               eps_masked=eps_m, eps_unmasked=eps_u, eps_null=eps_n, att_fp=fp(att))
+    print("   masked vs unmasked rel diff:", float((eps_m - eps_u).norm() / eps_u.norm()))
+    torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -334,6 +368,8 @@ def main():
         gen_vae_case("vae_tiny", "tiny", 8, 2)
         schema = gen_vae_case("vae_full_16", "full", 16, 1)
         json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "vae_schema.json"), "w"))
+    if args.only in ("all", "masked"):
+        gen_masked_case()
     if args.only in ("all", "input"):
         gen_input_case()
     print("done")

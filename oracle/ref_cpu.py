@@ -90,9 +90,9 @@ def fourier_embed(x: torch.Tensor, num_freqs: int = 16, temperature: float = 100
 # ------------------------------------------------------------------------------------------------
 # attention.py
 # ------------------------------------------------------------------------------------------------
-def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
-    """softmax(Q K^T / sqrt(d)) V per head, no mask (attention.py:120-157, 174-186, 257-282).
-    q [B,N,C], k/v [B,M,C] -> [B,N,C]."""
+def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(Q K^T / sqrt(d)) V per head (attention.py:120-157, 174-186, 257-282).  q [B,N,C], k/v [B,M,C] ->
+    [B,N,C].  ``mask`` [B,1,N,M]: scores where mask <= 0 are filled with -inf (non-efficient path, attention.py:276-277)."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
@@ -100,17 +100,47 @@ def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.
     kh = k.view(B, M, heads, d).permute(0, 2, 1, 3)
     vh = v.view(B, M, heads, d).permute(0, 2, 1, 3)
     s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+    if mask is not None:
+        s = s.masked_fill(mask <= 0.0, float("-inf"))
     p = torch.softmax(s, dim=-1)
     o = torch.matmul(p, vh)
     return o.permute(0, 2, 1, 3).reshape(B, N, C)
 
 
-def self_attention(sd: SD, p: str, x: torch.Tensor, heads: int) -> torch.Tensor:
-    """SelfAttention.forward, attention.py:174-282 (efficient path, mask None)."""
+def fuser_attention_mask(att_masks: torch.Tensor, n_tokens: int) -> Optional[torch.Tensor]:
+    """The instance-visibility mask of the masked gated self-attention, attention.py:187-255 (reached only with
+    ``efficient_attention=False``).  att_masks [B, n_objs, h, w] (binary, from utils/input.py:34-37); the sequence is
+    [h*w visual tokens | n_objs box | n_objs point | n_objs scribble | n_objs mask | 64 seg tokens].  Returns
+    [B, 1, N, N] or None when the reference would not mask (N - 4 n_objs - 64 != 64*64, or an all-zero mask)."""
+    B, n_objs = att_masks.shape[0], att_masks.shape[1]
+    N = n_tokens
+    if N - n_objs * 4 - 64 != 64 * 64:                               # :195 "brute-force" resolution check
+        return None
+    if not float(att_masks.sum()) > 0.0:                             # :200
+        return None
+    w_h = att_masks.shape[2] * att_masks.shape[3]
+    m = att_masks.reshape(B, n_objs, w_h).float()
+    mask = torch.ones(B, 1, N, N)
+    # :211-238 -- two visual tokens see each other iff at least one instance box contains both (the reference's
+    # sum_o m_o m_o^T >= 1, written as one matmul); tokens outside every box see no other visual token
+    ind = torch.einsum("bow,bov->bwv", m, m)
+    mask[:, 0, :w_h, :w_h] = (ind >= 1.0).float()
+    # :243-248 -- box tokens (first n_objs) and mask tokens (last n_objs of the 4 groups) are tied to their instance's
+    # box in both directions; point and scribble tokens (the two middle groups) and the 64 seg tokens stay visible
+    rep = m.repeat(1, 4, 1)                                          # [B, 4 n_objs, w_h]
+    mask[:, 0, w_h:N - 64, :w_h] = rep
+    mask[:, 0, w_h + n_objs:w_h + n_objs * 3, :w_h] = 1
+    mask[:, 0, :w_h, w_h:N - 64] = rep.transpose(1, 2)
+    mask[:, 0, :w_h, w_h + n_objs:w_h + n_objs * 3] = 1
+    return mask + torch.eye(N).view(1, 1, N, N) * 1e-9               # :251-252: a token always sees itself
+
+
+def self_attention(sd: SD, p: str, x: torch.Tensor, heads: int, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SelfAttention.forward, attention.py:174-282 (efficient path when ``mask`` is None, else :268-281)."""
     q = _lin(sd, p + ".to_q", x, bias=False)
     k = _lin(sd, p + ".to_k", x, bias=False)
     v = _lin(sd, p + ".to_v", x, bias=False)
-    return _lin(sd, p + ".to_out.0", mha(q, k, v, heads))
+    return _lin(sd, p + ".to_out.0", mha(q, k, v, heads, mask))
 
 
 def cross_attention(sd: SD, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int) -> torch.Tensor:
@@ -128,33 +158,37 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return _lin(sd, p + ".net.2", a * gelu_erf(gate))
 
 
-def gated_self_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """GatedSelfAttentionDense.forward, attention.py:304-311."""
+def gated_self_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, heads: int, scale: float,
+                         att_masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GatedSelfAttentionDense.forward, attention.py:304-311.  ``att_masks`` [B,n_objs,h,w]: masked variant
+    (efficient_attention=False and ``grounding_input['att_masks']`` present and boxes not dropped)."""
     n_vis = x.shape[1]
     o = _lin(sd, p + ".linear", objs)
-    a = self_attention(sd, p + ".attn", _ln(sd, p + ".norm1", torch.cat([x, o], dim=1)), heads)
+    seq = torch.cat([x, o], dim=1)
+    mask = None if att_masks is None else fuser_attention_mask(att_masks, seq.shape[1])
+    a = self_attention(sd, p + ".attn", _ln(sd, p + ".norm1", seq), heads, mask)
     x = x + scale * torch.tanh(sd[p + ".alpha_attn"]) * a[:, :n_vis]
     x = x + scale * torch.tanh(sd[p + ".alpha_dense"]) * feed_forward(sd, p + ".ff", _ln(sd, p + ".norm2", x))
     return x
 
 
-def transformer_block(sd: SD, p: str, x, ctx, objs, heads: int, scale: float):
+def transformer_block(sd: SD, p: str, x, ctx, objs, heads: int, scale: float, att_masks=None):
     """BasicTransformerBlock._forward, attention.py:333-338."""
     x = self_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), heads) + x
-    x = gated_self_attention(sd, p + ".fuser", x, objs, heads, scale)
+    x = gated_self_attention(sd, p + ".fuser", x, objs, heads, scale, att_masks)
     x = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", x), ctx, heads) + x
     x = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x
     return x
 
 
-def spatial_transformer(sd: SD, p: str, x, ctx, objs, heads: int, scale: float):
+def spatial_transformer(sd: SD, p: str, x, ctx, objs, heads: int, scale: float, att_masks=None):
     """SpatialTransformer.forward, attention.py:366-379."""
     b, c, h, w = x.shape
     x_in = x
     y = _gn32(sd, p + ".norm", x, 1e-6)
     y = _conv(sd, p + ".proj_in", y, padding=0)
     y = y.permute(0, 2, 3, 1).reshape(b, h * w, c)
-    y = transformer_block(sd, p + ".transformer_blocks.0", y, ctx, objs, heads, scale)
+    y = transformer_block(sd, p + ".transformer_blocks.0", y, ctx, objs, heads, scale, att_masks)
     y = y.reshape(b, h, w, c).permute(0, 3, 1, 2)
     y = _conv(sd, p + ".proj_out", y, padding=0)
     return y + x_in
@@ -247,7 +281,7 @@ def unet_layout(cfg) -> Dict[str, list]:
     return dict(input=inp, middle=mid, output=out, scaleu_ch=scaleu_ch, final_ch=ch)
 
 
-def _run_layers(sd: SD, prefix: str, layers, h, emb, ctx, objs, heads, scale):
+def _run_layers(sd: SD, prefix: str, layers, h, emb, ctx, objs, heads, scale, att_masks=None):
     """TimestepEmbedSequential.forward, openaimodel.py:62-79."""
     for j, layer in enumerate(layers):
         p = f"{prefix}.{j}"
@@ -257,7 +291,7 @@ def _run_layers(sd: SD, prefix: str, layers, h, emb, ctx, objs, heads, scale):
         elif kind == "res":
             h = res_block(sd, p, h, emb)
         elif kind == "st":
-            h = spatial_transformer(sd, p, h, ctx, objs, heads, scale)
+            h = spatial_transformer(sd, p, h, ctx, objs, heads, scale, att_masks)
         elif kind == "down":  # Downsample, openaimodel.py:115-141 (3x3 stride-2 pad-1 conv)
             h = _conv(sd, p + ".op", h, stride=2)
         elif kind == "up":    # Upsample, openaimodel.py:82-110 (nearest x2 then 3x3 conv)
@@ -271,9 +305,11 @@ def _run_layers(sd: SD, prefix: str, layers, h, emb, ctx, objs, heads, scale):
 def unet_forward(sd: SD, cfg, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor,
                  objs: torch.Tensor, fuser_scale: float = 1.0,
                  first_conv: Optional[Mapping[str, torch.Tensor]] = None,
-                 probes: Optional[dict] = None) -> torch.Tensor:
+                 probes: Optional[dict] = None, att_masks: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UNetModel.forward_single_input, openaimodel.py:482-563, with ``objs`` (UniFusion tokens) precomputed.
-    ``first_conv``: replacement {weight,bias} of input_blocks.0.0 (restore_first_conv_from_SD, :469-480)."""
+    ``first_conv``: replacement {weight,bias} of input_blocks.0.0 (restore_first_conv_from_SD, :469-480).
+    ``att_masks``: ``grounding_input['att_masks']`` for a model built with efficient_attention=False and boxes not
+    dropped (openaimodel.py:508-518,558-561 pass grounding_input down only then); None = the efficient path."""
     lay = unet_layout(cfg)
     heads = cfg["num_heads"]
     if first_conv is not None:
@@ -285,11 +321,11 @@ def unet_forward(sd: SD, cfg, x: torch.Tensor, timesteps: torch.Tensor, context:
     h = x
     hs = []
     for i, layers in enumerate(lay["input"]):
-        h = _run_layers(sd, f"input_blocks.{i}", layers, h, emb, context, objs, heads, fuser_scale)
+        h = _run_layers(sd, f"input_blocks.{i}", layers, h, emb, context, objs, heads, fuser_scale, att_masks)
         hs.append(h)
         if probes is not None:
             probes[f"input_blocks.{i}"] = h
-    h = _run_layers(sd, "middle_block", lay["middle"], h, emb, context, objs, heads, fuser_scale)
+    h = _run_layers(sd, "middle_block", lay["middle"], h, emb, context, objs, heads, fuser_scale, att_masks)
     if probes is not None:
         probes["middle_block"] = h
     for i, layers in enumerate(lay["output"]):
@@ -299,7 +335,7 @@ def unet_forward(sd: SD, cfg, x: torch.Tensor, timesteps: torch.Tensor, context:
         h = h * b[None, :, None, None]                   # :536
         skip = fourier_filter(skip, 1, s)                # :537
         h = torch.cat([h, skip], dim=1)                  # :539
-        h = _run_layers(sd, f"output_blocks.{i}", layers, h, emb, context, objs, heads, fuser_scale)
+        h = _run_layers(sd, f"output_blocks.{i}", layers, h, emb, context, objs, heads, fuser_scale, att_masks)
         if probes is not None:
             probes[f"output_blocks.{i}"] = h
     h = silu(_gn32(sd, "out.0", h, 1e-5))

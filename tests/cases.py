@@ -94,3 +94,21 @@ def build_vae(cfg: dict, salt: int = 7):
 def vae_latent(meta: dict) -> torch.Tensor:
     g = torch.Generator().manual_seed(4321)
     return torch.randn(meta["batch"], 4, meta["latent"], meta["latent"], generator=g) * 0.18215 * 4.0
+
+
+# ---- masked gated self-attention case (oracle/make_golden.py:gen_masked_case) ------------------------------------
+def build_masked_inputs():
+    import numpy as np
+    g = torch.Generator().manual_seed(1234)
+    bx = synth.random_boxes(3, g)
+    gb = synth.make_grounding_batch(1, bx, g)
+    att = torch.zeros(30, 64, 64)
+    for i in range(3):                                   # utils/input.py:34-37 index order (x on dim 0)
+        b = bx[i].tolist()
+        x1, y1, x2, y2 = (int(np.round(b[0] * 64)), int(np.round(b[1] * 64)), int(np.round(b[2] * 64)),
+                          int(np.round(b[3] * 64)))
+        att[i][x1:x2, y1:y2] = 1
+    gb["att_masks"] = att.unsqueeze(0)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    context = torch.randn(1, 77, 768, generator=g)
+    return dict(gb=gb, x=x, context=context, t=torch.full((1,), 981, dtype=torch.long))

@@ -89,8 +89,10 @@ class EmulOps:
         out.copy_(F.conv2d(x_nchw, w, bias, padding=1).permute(0, 2, 3, 1))
         return out
 
-    def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0):
+    def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0, qbits=None, kbits0=None, kbits1=None):
         self._count("attention")
+        if qbits is not None:
+            self._count("attention_masked")
         B, Nq, C = q.shape
         d = C // heads
         assert vt0.shape[-1] >= (n0 + 63) // 64 * 64
@@ -105,6 +107,15 @@ class EmulOps:
         kh = k.reshape(B, M, heads, d).permute(0, 2, 1, 3)
         vh = v.reshape(B, M, heads, d).permute(0, 2, 1, 3)
         s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+        if qbits is not None:                      # include/idf.h: visible iff words intersect, or own token (segment 0)
+            vis = (qbits[:, :, None] & kbits0[:, None, :n0]) != 0
+            idx = torch.arange(Nq)
+            own = torch.zeros(Nq, n0, dtype=torch.bool)
+            own[idx[idx < n0], idx[idx < n0]] = True
+            vis = vis | own[None]
+            if n1:
+                vis = torch.cat([vis, (qbits[:, :, None] & kbits1[:, None, :n1]) != 0], -1)
+            s = s.masked_fill(~vis[:, None], float("-inf"))
         mx = s.max(-1, keepdim=True).values
         p = torch.exp(s - mx)
         l = p.sum(-1, keepdim=True)

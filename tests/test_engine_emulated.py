@@ -15,9 +15,9 @@ from tests import cases
 from tests.emul_ops import EmulOps
 
 
-def build_model(cfg):
+def build_model(cfg, efficient_attention=True):
     with torch.device("meta"):
-        m = UNetModel(**unet_kwargs_from_cfg(cfg))
+        m = UNetModel(**dict(unet_kwargs_from_cfg(cfg), efficient_attention=efficient_attention))
     m = m.to_empty(device="cpu")
     m.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
     return m.eval()

@@ -146,10 +146,7 @@ def pmc_traffic(op_name, batch):
         return None
     try:
         tab = json.load(open(path))
-        ent = tab.get(str(batch), {}).get(op_name)
-        return None if ent is None else dict(hbm_bytes_per_launch=ent["hbm_bytes_per_launch"],
-                                             algorithmic_bytes_per_launch=ent.get("algorithmic_bytes_per_launch"),
-                                             source=ent.get("source"))
+        return tab.get(str(batch), {}).get(op_name)
     except Exception:
         return None
 
@@ -180,8 +177,13 @@ def measure_roofline(engine, batch):
             "attention": "attn2_kernel<.., LAZY> (64 queries/wave, LDS-DMA K/V^T, lazy rescaling) / attn_kernel for d=80,160"
             }.get(name, name)
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    pmc = pmc_traffic(name, batch)
+    # `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    # WRITE_SIZE, separate runs), averaged over the family's launches of one forward at this batch; null without a pass
     return dict(bound="mfma", kernel=kern, achieved=round(achieved, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
-                frac=round(achieved / PEAK_MFMA_TF, 4), traffic=pmc_traffic(name, batch),
+                frac=round(achieved / PEAK_MFMA_TF, 4),
+                traffic=None if pmc is None else float(pmc["hbm_bytes_per_launch"]), traffic_unit="bytes/launch",
+                traffic_source=None if pmc is None else pmc.get("source"),
                 launches_per_forward=d["calls"], avg_launch_us=round(d["ms"] * 1e3 / d["calls"], 2),
                 algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
                 algorithmic_mbytes_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2), measured_at_batch=batch,

@@ -61,12 +61,15 @@ def test_engine_masked_forward_emulated(dtype, tol):
     gi = GroundingNetInput()
     with torch.no_grad():
         cond = eng.prepare_cond(inp["context"], gi.prepare(inp["gb"], return_att_masks=True))
-        eps = eng.forward_cond(inp["x"], inp["t"], cond)
-        assert cases.rel_rms(eps, gold["eps_masked"]) < tol
-        null = eng.prepare_cond(inp["context"], gi.get_null_input())           # zero att_masks -> unmasked
-        assert cases.rel_rms(eng.forward_cond(inp["x"], inp["t"], null), gold["eps_null"]) < tol
+        if dtype != torch.float32:                                             # storage-rounding check: one forward
+            assert cases.rel_rms(eng.forward_cond(inp["x"], inp["t"], cond), gold["eps_masked"]) < tol
+            return
+        # masked sample and null-grounding sample (zero att_masks -> unmasked, attention.py:200) in ONE batched forward
+        null = eng.prepare_cond(inp["context"], gi.get_null_input())
         both = eng.forward_cond(torch.cat([inp["x"]] * 2), torch.cat([inp["t"]] * 2), type(cond).cat([cond, null]))
         assert cases.rel_rms(both[:1], gold["eps_masked"]) < tol and cases.rel_rms(both[1:], gold["eps_null"]) < tol
+        assert eng.ops.calls["attention_masked"] == sum(1 for p in eng._st_layers() if p["c"] == cfg["model_channels"])
+        # a grounding input WITHOUT att_masks on the same model is the unmasked path
         plain = eng.prepare_cond(inp["context"], gi.prepare({k: v for k, v in inp["gb"].items() if k != "att_masks"}))
         assert cases.rel_rms(eng.forward_cond(inp["x"], inp["t"], plain), gold["eps_unmasked"]) < tol
 

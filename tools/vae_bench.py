@@ -21,8 +21,13 @@ GFLOP_PER_IMAGE = 2514.5
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    from tests import cases                      # seeded synthetic weights (no checkpoints offline)
-    ae = cases.build_vae(cases.vae_cfg_for("full"))
+    from instancediffusion_amd import synth     # seeded synthetic weights (no checkpoints offline)
+    from instancediffusion_amd.host.config import instantiate_from_config, load_yaml
+    cfg = load_yaml(os.path.join(REPO, "configs", "test_box.yaml"))
+    with torch.device("meta"):
+        ae = instantiate_from_config(cfg["autoencoder"])
+    ae.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in ae.state_dict().items()}, 7), assign=True)
+    ae.eval()
     ae.max_decode_batch = B
     z = torch.randn(B, 4, 64, 64, device="cuda") * 0.18215 * 4
     ae.decode(z)                                 # warm-up + graph capture

@@ -95,7 +95,7 @@ class EmulOps:
             self._count("attention_masked")
         B, Nq, C = q.shape
         d = C // heads
-        assert vt0.shape[-1] >= (n0 + 63) // 64 * 64
+        assert vt0.shape[-1] >= (n0 + 63) // 64 * 64 or vt0.stride(1) >= (n0 + 63) // 64 * 64
         k = k0.float()[:, :n0]
         v = vt0.float()[:, :, :n0].transpose(1, 2)
         if n1:

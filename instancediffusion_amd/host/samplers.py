@@ -195,21 +195,8 @@ class PLMSSamplerInst(_PLMSBase):
         alphas = self.alpha_generator_func(len(time_range)) if self.alpha_generator_func is not None else None
         mis_step = int(total * self.mis)
 
-        conds = [self._cond(inp) for inp in input_all]
-        cond_u = self._uncond(uc) if guided else None
-        CondT = type(conds[0])
-        # one bank of all conditionings; batches are assembled by a single row gather straight into the engine's
-        # static slot: row j*B + b = (instance j, image b), row n_all*B + b = unconditional of image b
-        bank = CondT.cat(conds + ([cond_u] if guided else []))
-
-        def rows(units):
-            r = [j * B + b for (j, b) in units]
-            if guided:
-                r += [n_all * B + b for (_, b) in units]
-            return torch.tensor(r, device=dev, dtype=torch.long)
-
-        # ---------------- phase 1: N+1 independent trajectories per image (plms_instance.py:86-104) ----------
-        # work unit = (instance j, image b).  "image" sharding: owner = b % world -- every trajectory of an image lives on
+        # ---------------- work split (decided BEFORE any conditioning is built) ---------------------------------
+        # Phase 1 = N+1 independent trajectories per image (plms_instance.py:86-104); work unit = (instance j, image b).  "image" sharding: owner = b % world -- every trajectory of an image lives on
         # the rank that also runs its phase 2, the first-evaluation hoist touches only this rank's images and per-rank work
         # is independent of the world size (weak scaling); used when the images divide evenly over the ranks.
         # "instance" sharding: owner = (b + j) % world -- spreads the N+1 trajectories of FEW images (B < world, e.g. one
@@ -222,6 +209,44 @@ class PLMSSamplerInst(_PLMSBase):
             units = [(j, b) for j in range(n_all) for b in range(B) if b % world == rank]
         else:
             units = [(j, b) for j in range(n_all) for b in range(B) if (b + j) % world == rank]
+        mine = [b for b in range(B) if b % world == rank]                     # images this rank owns in phase 2
+
+        # Conditioning (UniFusion tokens + per-layer K/V caches) only for the images THIS rank touches: with image
+        # sharding that is B / world images, so per-rank setup work and HBM stay constant as ranks are added (weak
+        # scaling); with one rank it is every image.  One bank of all conditionings; batches are assembled by a single
+        # row gather straight into the engine's static slot: row j*Bl + loc[b] = (instance j, image b),
+        # row n_all*Bl + loc[b] = unconditional of image b.
+        need = sorted({b for (_, b) in units} | set(mine))
+        loc = {b: k for k, b in enumerate(need)}
+        Bl = len(need)
+        sel = torch.tensor(need, device=dev, dtype=torch.long)
+
+        def take(v):
+            if not torch.is_tensor(v) or v.dim() == 0 or v.shape[0] != B or Bl == B:
+                return v
+            if v.stride(0) == 0:                                               # batch-broadcast view stays a view
+                return v[:1].expand(Bl, *v.shape[1:])
+            return v.index_select(0, sel.to(v.device))
+
+        def local(inp):
+            d = dict(inp)
+            d["context"] = take(inp["context"])
+            if "grounding_input" in inp:
+                d["grounding_input"] = {k: take(v) for k, v in inp["grounding_input"].items()}
+            else:
+                d["grounding_input"] = self.model.grounding_tokenizer_input.get_null_input(batch=Bl)
+            return d
+
+        conds = [self._cond(local(inp)) for inp in input_all] if Bl else []
+        cond_u = self._uncond(take(uc)) if (guided and Bl) else None
+        bank = type(conds[0]).cat(conds + ([cond_u] if guided else [])) if Bl else None
+
+        def rows(units):
+            r = [j * Bl + loc[b] for (j, b) in units]
+            if guided:
+                r += [n_all * Bl + loc[b] for (_, b) in units]
+            return torch.tensor(r, device=dev, dtype=torch.long)
+
         # Reference quirk: restore_first_conv_from_SD is never undone, so if alpha hits 0 inside phase 1 the LATER
         # instances would run their EARLY steps with the swapped conv.  Only then is the serial order observable;
         # reproduce it by advancing one instance at a time.
@@ -243,7 +268,7 @@ class PLMSSamplerInst(_PLMSBase):
         if guided and same_start and units and mis_step > 0 and not serial:
             self._apply_alpha(alphas, 0)
             imgs = sorted({b for (_, b) in units})
-            row_ids = [j * B + b for (j, b) in units] + [n_all * B + b for b in imgs]
+            row_ids = [j * Bl + loc[b] for (j, b) in units] + [n_all * Bl + loc[b] for b in imgs]
             row_img = [b for (_, b) in units] + imgs
             first_idx = {u: k for k, u in enumerate(units)}
             first_unc = {b: len(units) + k for k, b in enumerate(imgs)}
@@ -284,7 +309,6 @@ class PLMSSamplerInst(_PLMSBase):
                 eps_units[u] = [e[k] for e in old]
 
         # ---------------- merge (plms_instance.py:128-135) ------------------------------------------------------
-        mine = [b for b in range(B) if b % world == rank]                     # images this rank owns in phase 2
         if self.crop_and_paste_latents:
             lat = torch.zeros((n_all, B) + tuple(shape[1:]), device=dev, dtype=torch.float32)
             for (j, b), xv in x_units.items():

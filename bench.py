@@ -53,26 +53,35 @@ def build_model(cfg):
 
 
 def make_inputs(cfg, n_images, device):
-    """Seeded synthetic C3 inputs: N random boxes, random text embeddings / contexts, shared noise."""
+    """Seeded synthetic C3 inputs: N random boxes, random text embeddings / contexts, shared noise.
+
+    Every image of the batch carries the same grounding (as ``utils/input.py:prepare_batch`` produces: one meta
+    repeated ``batch`` times), so the grounding tensors are built for ONE sample: the small ones are repeated on the
+    device, the 30 x 512 x 512 mask stack (31 MB per sample) is a stride-0 batch broadcast -- the reference's
+    ``.repeat`` layout would cost 9 inputs x 31 MB x images of host AND device memory per rank (72 GB at 256 images)."""
     from instancediffusion_amd import synth
     from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
     g = torch.Generator().manual_seed(1234)
     boxes = synth.random_boxes(N_INST, g)
-    gb = synth.make_grounding_batch(n_images, boxes, g)
+    gb1 = synth.make_grounding_batch(1, boxes, g)
     x = torch.randn(n_images, 4, LATENT, LATENT, generator=g)
     ctx = torch.randn(n_images, 77, 768, generator=g)
     uc = torch.randn(n_images, 77, 768, generator=g)
     inst_ctx = [torch.randn(n_images, 77, 768, generator=g) for _ in range(N_INST)]
     gi = GroundingNetInput()
 
-    def dev(d):
-        return {k: v.to(device) for k, v in d.items()}
-    inputs = [dict(x=x.to(device), timesteps=None, context=ctx.to(device), grounding_input=gi.prepare(dev(gb)))]
+    def dev(d1):
+        out = {}
+        for k, v in d1.items():
+            v = v.to(device)
+            out[k] = v.expand(n_images, *v.shape[1:]) if k == "segs" else v.repeat(n_images, *([1] * (v.dim() - 1)))
+        return out
+    inputs = [dict(x=x.to(device), timesteps=None, context=ctx.to(device), grounding_input=gi.prepare(dev(gb1)))]
     for i in range(N_INST):
         inputs.append(dict(x=x.to(device), timesteps=None, context=inst_ctx[i].to(device),
-                           grounding_input=gi.prepare(dev(synth.instance_batch(gb, i)))))
-    gi.prepare(dev(gb))
-    return inputs, uc.to(device), gi, dict(gb=gb, x=x, ctx=ctx)
+                           grounding_input=gi.prepare(dev(synth.instance_batch(gb1, i)))))
+    gi.prepare(dev(gb1))
+    return inputs, uc.to(device), gi, dict(gb=gb1, x=x, ctx=ctx)
 
 
 class OpTimer:

@@ -83,6 +83,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
             f"(run instancediffusion_amd/csrc/build.sh or __graft_entry__.build()). "
             f"There is no CPU fallback for the InstanceDiffusion sampling path.")
+    # PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be in the process BEFORE this
+    # library is dlopen'ed so that our DT_NEEDED entry resolves to that one runtime; loaded the other way round the
+    # process holds two HIP runtimes and launches on torch's streams fail with hipErrorNoDevice (seen on the GPU box
+    # when build() ran before the first `import torch`).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.idf_build_info()
 
 
+def test_single_hip_runtime_whatever_the_import_order():
+    """Loading the C-ABI library before the caller ever imported torch must not bring a second libamdhip64 into the
+    process (two runtimes -> hipErrorNoDevice on torch's streams)."""
+    import subprocess
+    import sys
+    code = ("import instancediffusion_amd._lib as L; L.load(); import torch; "
+            "m = {l.split()[-1] for l in open('/proc/self/maps') if 'amdhip64' in l}; print(len(m))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
+
+
 def test_argument_validation_without_gpu():
     from instancediffusion_amd import _lib
     lib = _lib.load()

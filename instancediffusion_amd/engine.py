@@ -427,7 +427,8 @@ class UNetEngine:
         c.objs = self.tokens(grounding)
         if self.masked_fuser:
             # attention.py:187-255: instance-visibility mask of the fuser attention, as membership words.  A grounding
-            # input without att_masks, with boxes dropped (eval-mode drop_box_mask) or all-zero masks is unmasked.
+            # input (= one reference model call) without att_masks, with boxes dropped (eval-mode drop_box_mask) or
+            # with an all-zero mask tensor is unmasked; conds of different calls are concatenated row-wise later.
             from .host.attention import visibility_words
             am = grounding.get("att_masks")
             if am is None or self.pn.eval_drops()[1]:

@@ -115,15 +115,17 @@ def visibility_words(att_masks: torch.Tensor, n_groups: int = 4, n_seg_tokens: i
         kbits1 [B, ceil64(4 n_objs + 64)]  per grounding token: box token o -> bit o, point / scribble tokens -> all
                            ones, mask token o -> bit o, the 64 seg tokens -> all ones (padding -> all ones),
     such that query q sees key k iff ``(qbits[q] & kbits[k]) != 0`` or k is q itself -- exactly ``mask > 0`` of
-    attention.py:206-253 for the visual query rows (the only rows attention.py:308 keeps).  A sample whose mask stack is
-    all zero is unmasked in the reference (:200): all its words are all-ones."""
+    attention.py:206-253 for the visual query rows (the only rows attention.py:308 keeps).  The reference decides PER
+    CALL whether to mask at all (``torch.sum(att_masks) > 0`` over the whole batch tensor, :200): an all-zero tensor (the
+    null grounding input of the unconditional branch) gives all-ones words = no mask; otherwise every sample is masked,
+    and a sample without any instance pixel sees only itself, the point / scribble tokens and the seg tokens."""
     B, n_objs = att_masks.shape[0], att_masks.shape[1]
     assert n_objs <= 31, "one bit per instance, bit 31 reserved"
     dev = att_masks.device
     m = (att_masks.reshape(B, n_objs, -1) > 0)
     weights = (torch.ones(n_objs, dtype=torch.int64, device=dev) << torch.arange(n_objs, device=dev)).view(1, n_objs, 1)
     inst = (m.to(torch.int64) * weights).sum(1)                                        # [B, hw], < 2^31
-    unmasked = ~m.reshape(B, -1).any(1)                                                # [B]
+    unmasked = (~m.any()).expand(B)                                                    # [B], one decision per call
     full = torch.full_like(inst, 0xFFFFFFFF)
     q64 = torch.where(unmasked[:, None], full, inst | 0x80000000)
     k64 = torch.where(unmasked[:, None], full, inst)

@@ -44,7 +44,7 @@ def test_bit_words_reproduce_the_dense_mask():
     vis0 |= torch.eye(4096, dtype=torch.bool)[None]
     vis1 = (qb[:, :, None] & kb1[:, None, :184]) != 0
     assert torch.equal(torch.cat([vis0, vis1], -1), dense)
-    # an all-zero mask stack means "no mask" in the reference (attention.py:200): every word pair must intersect
+    # an all-zero mask TENSOR means "no mask" in the reference (attention.py:200): every word pair must intersect
     qz, kz0, kz1 = visibility_words(torch.zeros_like(att))
     assert bool(((qz[:, :, None] & kz0[:, None, :64]) != 0).all()) and bool(((qz[:, :1, None] & kz1[:, None, :184]) != 0).all())
 
@@ -130,3 +130,18 @@ def test_engine_masked_forward_gpu():
     err, err_n = cases.rel_rms(eps.float().cpu(), gold["eps_masked"]), cases.rel_rms(eps_n.float().cpu(), gold["eps_null"])
     print(f"[parity] masked gated self-attention forward bf16: rel-rms {err:.3e}; null grounding {err_n:.3e}")
     assert torch.equal(eps, eps2) and err < 3e-2 and err_n < 3e-2
+
+
+def test_bit_words_random_masks_property():
+    """Random (overlapping, partly empty) instance masks on a small grid: words == dense reference mask."""
+    from instancediffusion_amd.host.attention import visibility_words
+    g = torch.Generator().manual_seed(11)
+    for n_objs in (1, 7, 30):
+        att = (torch.rand(2, n_objs, 64, 64, generator=g) < 0.08).float()
+        att[1, n_objs // 2] = 0       # an instance with an empty mask (n_objs == 1: a sample with NO instance pixel)
+        dense = ref_cpu.fuser_attention_mask(att, 4096 + 4 * n_objs + 64)[:, 0, :4096] > 0
+        qb, kb0, kb1 = visibility_words(att)
+        n1 = 4 * n_objs + 64
+        vis0 = ((qb[:, :, None] & kb0[:, None, :]) != 0) | torch.eye(4096, dtype=torch.bool)[None]
+        vis1 = (qb[:, :, None] & kb1[:, None, :n1]) != 0
+        assert torch.equal(torch.cat([vis0, vis1], -1), dense), n_objs

@@ -229,8 +229,12 @@ def gen_vae_case(tag: str, variant: str, latent: int, batch: int):
     img = ae.decode(z)
     for h in hooks:
         h.remove()
-    out = dict(meta=dict(tag=tag, variant=variant, latent=latent, batch=batch, z_fp=fp(z), salt=7),
-               img=img.clone(), probes=probes)
+    out = dict(meta=dict(tag=tag, variant=variant, latent=latent, batch=batch, z_fp=fp(z), salt=7), probes=probes)
+    if img.numel() > 400000:        # full-size image (3 MB): keep an 8x8 average-pooled digest + moments instead
+        out["img_pool8"] = torch.nn.functional.avg_pool2d(img, 8).clone()
+        out["img_fp"] = fp(img)
+    else:
+        out["img"] = img.clone()
     torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
     return schema
 
@@ -367,6 +371,7 @@ def main():
     if args.only in ("all", "vae"):
         gen_vae_case("vae_tiny", "tiny", 8, 2)
         schema = gen_vae_case("vae_full_16", "full", 16, 1)
+        gen_vae_case("vae_full_64", "full", 64, 1)              # the reference's real call: 64x64 latent -> 512x512
         json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "vae_schema.json"), "w"))
     if args.only in ("all", "masked"):
         gen_masked_case()

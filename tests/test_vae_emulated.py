@@ -61,3 +61,18 @@ def test_vae_decode_refuses_without_hip():
         ae.decode(torch.zeros(1, 4, 8, 8))
     with pytest.raises(NotImplementedError):
         ae.encode(torch.zeros(1, 3, 64, 64))
+
+
+def test_oracle_vae_decode_full_size_vs_reference_digest():
+    """The reference's real call (inference.py:95): 64x64 latent -> 512x512 image; golden kept as an 8x8 average-pooled
+    digest + moments (the full image would be 3 MB)."""
+    gold = cases.load_golden("vae_full_64")
+    meta = gold["meta"]
+    cfg = cases.vae_cfg_for("full")
+    ae = cases.build_vae(cfg, meta["salt"])
+    with torch.no_grad():
+        img = ref_cpu.vae_decode({k: v.detach() for k, v in ae.state_dict().items()}, cfg, cases.vae_latent(meta))
+    assert list(img.shape) == gold["img_fp"]["shape"] == [1, 3, 512, 512]
+    assert cases.rel_rms(torch.nn.functional.avg_pool2d(img, 8), gold["img_pool8"]) < 2e-4
+    assert abs(float(img.std()) - gold["img_fp"]["std"]) < 1e-4 * gold["img_fp"]["std"] + 1e-6
+    assert torch.allclose(img.flatten()[:32], gold["img_fp"]["head"], atol=1e-4, rtol=1e-4)

@@ -194,3 +194,19 @@ def test_vae_decode_full_size_properties():
     img2 = ae.decode(z.cuda())
     # a different batch size takes different tile schedules only in fp32 summation order -> 16-bit-level agreement
     assert cases.rel_rms(img2.float().cpu(), img.float().cpu()) < 1e-2
+
+
+def test_vae_decode_full_size_vs_reference_digest():
+    """64x64 latent -> 512x512 image against the digest of the unmodified reference's decode (8x8 average pooling of
+    the image, its std and its first 32 pixels): parity AT the full size, not only properties."""
+    from tests import cases
+    gold = cases.load_golden("vae_full_64")
+    meta = gold["meta"]
+    ae = cases.build_vae(cases.vae_cfg_for("full"), meta["salt"])
+    img = ae.decode(cases.vae_latent(meta).cuda()).float().cpu()
+    err = cases.rel_rms(torch.nn.functional.avg_pool2d(img, 8), gold["img_pool8"])
+    std_err = abs(float(img.std()) - gold["img_fp"]["std"]) / gold["img_fp"]["std"]
+    head_err = float((img.flatten()[:32] - gold["img_fp"]["head"]).abs().max()) / gold["img_fp"]["absmax"]
+    print(f"[parity] VAE decode 64x64 latent bf16 vs reference digest: pooled rel-rms {err:.3e}, std {std_err:.2e}, "
+          f"first pixels {head_err:.2e} of max")
+    assert torch.isfinite(img).all() and err < 3e-2 and std_err < 2e-2 and head_err < 5e-2

@@ -105,71 +105,64 @@ def _t(v) -> torch.Tensor:
     return torch.as_tensor(np.asarray(v), dtype=torch.float32)
 
 
+def _padded_slots(entries, max_objs: int, text_mask_spec, att_rows=None, image_size: int = 64) -> Dict[str, torch.Tensor]:
+    """One sample's [max_objs, ...] grounding tensors.  ``entries``: per live instance a tuple
+    (box, text_feature | None, polygon | None, scribble | None, seg | None, point | None); slot k takes entry k, the
+    remaining slots stay zero (``create_zero_input_tensors``).  ``att_rows``: optional per-entry [S, S] visibility
+    masks for the masked gated self-attention."""
+    (boxes, masks, text_masks, text_emb, polygons, scribbles, segs, points) = create_zero_input_tensors(
+        max_objs, N_POLYGON_POINTS, N_SCRIBBLE_POINTS)
+    fields = (None, None, polygons, scribbles, segs, points)
+    for k, entry in enumerate(entries):
+        boxes[k] = _t(entry[0])
+        masks[k] = 1
+        if entry[1] is not None:
+            text_emb[k] = entry[1].detach().float().cpu().reshape(-1)
+            text_masks[k] = 1
+        for dst, val in zip(fields[2:], entry[2:]):
+            if val is not None:
+                dst[k] = _t(val).reshape(dst[k].shape)
+    out = dict(boxes=boxes, masks=masks, text_masks=text_masks * complete_mask(text_mask_spec, max_objs)[0],
+               text_embeddings=text_emb, polygons=polygons, scribbles=scribbles, segs=segs, points=points)
+    if att_rows is not None:
+        att = torch.zeros(max_objs, image_size, image_size)
+        for k, row in enumerate(att_rows):
+            att[k] = row
+        out["att_masks"] = att
+    return out
+
+
+N_SCRIBBLE_POINTS, N_POLYGON_POINTS = 20, 256
+
+
 @torch.no_grad()
 def prepare_batch(meta, batch=1, max_objs=30, model=None, processor=None, image_size=64, use_masked_att=False,
                   device="cuda"):
-    """utils/input.py:39-125."""
-    n_scribble_points, n_polygon_points = 20, 256
+    """utils/input.py:39-125: meta (phrases, locations, polygons, scribbles, segs, points[, text_mask,
+    instance_meta]) -> ``{boxes, masks, text_masks, text_embeddings, polygons, scribbles, segs, points[, att_masks,
+    instance_meta: [same dict per instance]]}``, every tensor [batch, max_objs, ...] on ``device``."""
     phrases = meta.get("phrases")
-    polygons, scribbles, segs, points = meta.get("polygons"), meta.get("scribbles"), meta.get("segs"), meta.get("points")
-    phrases = [None] * len(phrases) if phrases is None else phrases
-
-    (boxes, masks, text_masks, text_embeddings, polygons_embeddings, scribbles_embeddings, segs_embeddings,
-     points_embeddings) = create_zero_input_tensors(max_objs, n_polygon_points, n_scribble_points)
-    att_masks = torch.zeros(max_objs, image_size, image_size) if use_masked_att else None
-
+    phrases = [None] * len(meta["locations"]) if phrases is None else phrases
     text_features = [get_clip_feature(model, processor, phrase, is_image=False) for phrase in phrases]
-    for idx, (box, text_feature, polygon, scribble, seg, point) in enumerate(
-            zip(meta["locations"], text_features, polygons, scribbles, segs, points)):
-        boxes[idx] = _t(box)
-        masks[idx] = 1
-        if text_feature is not None:
-            text_embeddings[idx] = text_feature.detach().float().cpu().reshape(-1)
-            text_masks[idx] = 1
-        if polygon is not None:
-            polygons_embeddings[idx] = _t(polygon)
-        if scribble is not None:
-            scribbles_embeddings[idx] = _t(scribble).reshape(-1)
-        if seg is not None:
-            segs_embeddings[idx] = _t(seg)
-        if point is not None:
-            points_embeddings[idx] = _t(point)
-        if use_masked_att:
-            att_masks = get_attmask_w_box(att_masks, idx, box, image_size)
-
-    out: Dict[str, Any] = _batched(dict(
-        boxes=boxes, masks=masks, text_masks=text_masks * complete_mask(meta.get("text_mask"), max_objs)[0],
-        text_embeddings=text_embeddings, polygons=polygons_embeddings, scribbles=scribbles_embeddings,
-        segs=segs_embeddings, points=points_embeddings), batch, device)
-
+    entries = list(zip(meta["locations"], text_features, meta.get("polygons"), meta.get("scribbles"), meta.get("segs"),
+                       meta.get("points")))
+    att_rows = None
+    if use_masked_att:                                   # one box-shaped visibility plane per instance (:34-37)
+        planes = torch.zeros(len(entries), image_size, image_size)
+        for k, e in enumerate(entries):
+            get_attmask_w_box(planes, k, e[0], image_size)
+        att_rows = list(planes)
+    out: Dict[str, Any] = _batched(_padded_slots(entries, max_objs, meta.get("text_mask"), att_rows, image_size),
+                                   batch, device)
     if "instance_meta" in meta:
+        # the Multi-instance Sampler's per-instance inputs: instance i alone, in slot 0 (:92-120)
         out["instance_meta"] = []
-        for i in range(len(meta["instance_meta"])):
-            im = meta["instance_meta"][i]
-            (boxes_, masks_, text_masks_, text_embeddings_, polygons_embeddings_, scribbles_embeddings_,
-             segs_embeddings_, points_embeddings_) = create_zero_input_tensors(max_objs, n_polygon_points,
-                                                                                n_scribble_points)
-            boxes_[0] = _t(im["locations"][0])
-            polygons_embeddings_[0] = _t(im["polygons"][0])
-            scribbles_embeddings_[0] = _t(im["scribbles"][0]).reshape(-1)
-            segs_embeddings_[0] = _t(im["segs"][0])
-            points_embeddings_[0] = _t(im["points"][0])
-            masks_[0] = 1
-            if text_features[i] is not None:
-                text_masks_[0] = 1
-                text_embeddings_[0] = text_features[i].detach().float().cpu().reshape(-1)
-            d = dict(boxes=boxes_, masks=masks_,
-                     text_masks=text_masks_ * complete_mask(im.get("text_mask"), max_objs)[0],
-                     text_embeddings=text_embeddings_, polygons=polygons_embeddings_, scribbles=scribbles_embeddings_,
-                     segs=segs_embeddings_, points=points_embeddings_)
-            if use_masked_att:
-                att_masks_ = torch.zeros(max_objs, image_size, image_size)
-                att_masks_[0] = att_masks[i]
-                d["att_masks"] = att_masks_
-            out["instance_meta"].append(_batched(d, batch, device))
-
-    if use_masked_att:
-        out.update(_batched(dict(att_masks=att_masks), batch, device))
+        for i, im in enumerate(meta["instance_meta"]):
+            entry = (im["locations"][0], text_features[i], im["polygons"][0], im["scribbles"][0], im["segs"][0],
+                     im["points"][0])
+            one = _padded_slots([entry], max_objs, im.get("text_mask"), None if att_rows is None else [att_rows[i]],
+                                image_size)
+            out["instance_meta"].append(_batched(one, batch, device))
     return out
 
 

@@ -145,3 +145,29 @@ def test_bit_words_random_masks_property():
         vis0 = ((qb[:, :, None] & kb0[:, None, :]) != 0) | torch.eye(4096, dtype=torch.bool)[None]
         vis1 = (qb[:, :, None] & kb1[:, None, :n1]) != 0
         assert torch.equal(torch.cat([vis0, vis1], -1), dense), n_objs
+
+
+def test_visibility_words_travel_with_the_conditioning_bank():
+    """The samplers assemble [cond | uncond] / per-unit batches by row-gathering a bank of conditionings into the
+    engine's static slots: the visibility words must be gathered like every other per-sample tensor (first gather
+    allocates the slot, later gathers write it in place -- the hipGraph-visible path)."""
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    from instancediffusion_amd.engine import UNetEngine
+    from tests.emul_ops import EmulOps
+    from tests.test_engine_emulated import build_model
+    _, cfg, inp = _setup()
+    model = build_model(cfg, efficient_attention=False)
+    eng = UNetEngine(model, ops=EmulOps(torch.float32), use_graphs=False)
+    gi = GroundingNetInput()
+    with torch.no_grad():
+        cond = eng.prepare_cond(inp["context"], gi.prepare(inp["gb"], return_att_masks=True))
+        null = eng.prepare_cond(inp["context"], gi.get_null_input())
+    assert len(cond.vis) == 3 and cond.vis[0].dtype == torch.int32 and cond.vis[0].shape == (1, 4096)
+    assert bool((null.vis[0] == -1).all()) and not bool((cond.vis[0] == -1).all())
+    bank = type(cond).cat([cond, null])
+    slot = eng.gather_cond(bank, torch.tensor([1, 0, 0]))
+    for k in range(3):
+        assert torch.equal(slot.vis[k][0], null.vis[k][0]) and torch.equal(slot.vis[k][2], cond.vis[k][0])
+    slot2 = eng.gather_cond(bank, torch.tensor([0, 1, 1]))                    # same batch size: in-place refill
+    assert slot2 is slot and torch.equal(slot.vis[0][0], cond.vis[0][0]) and torch.equal(slot.vis[2][1], null.vis[2][0])
+    assert torch.equal(slot.objs[1], null.objs[0])

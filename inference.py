@@ -60,15 +60,16 @@ class ClipPhraseEncoder:
 
 
 def get_model_inputs(meta, gi, text_encoder, phrase_encoder, num_images, device, starting_noise, negative_prompt=None,
-                     instance_input=False):
-    """inference.py:39-78."""
+                     instance_input=False, use_masked_att=False):
+    """inference.py:39-78.  ``use_masked_att``: also build the box-shaped visibility planes and hand them to the model
+    (``eval_local.py --use_masked_att``; the reference's inference.py builds them but never passes them on)."""
     batch = prepare_batch(meta, batch=num_images, max_objs=MAX_OBJS, model=phrase_encoder, processor=None,
-                          image_size=starting_noise.shape[-1], use_masked_att=False, device=device)
+                          image_size=starting_noise.shape[-1], use_masked_att=use_masked_att, device=device)
     context = text_encoder.encode([meta["prompt"]] * num_images).to(device)
     uc = None
     if not instance_input:
         uc = text_encoder.encode(num_images * [negative_prompt if negative_prompt is not None else ""]).to(device)
-    grounding_input = gi.prepare(batch)
+    grounding_input = gi.prepare(batch, return_att_masks=use_masked_att)
     return dict(x=starting_noise, timesteps=None, context=context, grounding_input=grounding_input), uc
 
 
@@ -108,6 +109,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--save_latents", action="store_true")
+    ap.add_argument("--use_masked_att", action="store_true",
+                    help="masked gated self-attention (attention.py:187-255): instance patches only see their own box")
     args = ap.parse_args()
     if args.cascade_strength > 0:
         raise SystemExit("the SDXL refiner cascade is outside the sampling path (needs diffusers + downloads)")
@@ -138,6 +141,9 @@ def main():
         raise SystemExit("give --ckpt instancediffusion_sd15.pth, or --synthetic_weights for a dry run")
     model.compute_dtype = dtype
     autoencoder.compute_dtype = dtype
+    if args.use_masked_att:
+        model.efficient_attention = False      # the reference builds the mask only on its non-efficient path (:189)
+        model.invalidate_engine()
     gi = instantiate_from_config(cfg["grounding_tokenizer_input"])
     model.grounding_tokenizer_input = gi
     text_encoder = clip_text if use_clip else SyntheticTextEncoder()
@@ -150,7 +156,7 @@ def main():
     starting_noise = torch.randn(args.num_images, 4, model.image_size, model.image_size).to(dev)
 
     inp, uc = get_model_inputs(meta, gi, text_encoder, phrase_encoder, args.num_images, dev, starting_noise,
-                               args.negative_prompt)
+                               args.negative_prompt, use_masked_att=args.use_masked_att)
     ag = partial(alpha_generator, type=meta["alpha_type"])
     shape = (args.num_images, model.in_channels, model.image_size, model.image_size)
     if args.mis > 0:
@@ -158,7 +164,7 @@ def main():
         inputs = [inp]
         for i in range(len(meta["phrases"])):
             inst, _ = get_model_inputs(prepare_instance_meta(meta, i), gi, text_encoder, phrase_encoder, args.num_images,
-                                       dev, starting_noise, instance_input=True)
+                                       dev, starting_noise, instance_input=True, use_masked_att=args.use_masked_att)
             inputs.append(inst)
         samples = sampler.sample(S=args.steps, shape=shape, input=inputs, uc=uc, guidance_scale=args.guidance_scale)
     else:

@@ -317,7 +317,7 @@ def main():
         if not args.no_roofline:
             phase1_batch = max(model.engine._slots.keys())
             line["roofline"] = measure_roofline(model.engine, phase1_batch)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # reported at N=1 only (the host cores are shared at N>1)
             line["cpu_baseline"] = cpu_baseline(cfg, sd, host_inputs)
         print(json.dumps(line), flush=True)
     if world > 1:

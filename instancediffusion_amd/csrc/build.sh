@@ -1,17 +1,30 @@
 #!/bin/bash
 # Build libidf_gfx950.so (all HIP kernels + the C ABI) for gfx950.  hipcc cross-compiles without a GPU.
+# Incremental by default (a file is recompiled when it or a header is newer than its object); `build.sh --clean`
+# recompiles everything.  A failed compile fails the build: the stale object is removed first and every PID is waited for.
 set -e
 cd "$(dirname "$0")"
 OUT=../libidf_gfx950.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
+[ "$1" = "--clean" ] && rm -rf build
+mkdir -p build
 OBJS=""
+PIDS=""
 for f in gemm_conv gemm_big attention attention2 norms scaleu misc convnext; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_core.h -nt build/$f.o ] || [ attn_core.h -nt build/$f.o ] || [ ../../include/idf.h -nt build/$f.o ]; then
-    mkdir -p build
+  stale=0
+  [ -f build/$f.o ] || stale=1
+  for dep in $f.hip common.h gemm_core.h attn_core.h ../../include/idf.h; do
+    [ $dep -nt build/$f.o ] && stale=1
+  done
+  if [ $stale = 1 ]; then
+    rm -f build/$f.o
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o build/$f.o &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS build/$f.o"
 done
-wait
+for pid in $PIDS; do
+  wait $pid || { echo "build.sh: a compile failed" >&2; exit 1; }
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
 echo "built $(readlink -f $OUT)"

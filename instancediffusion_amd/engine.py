@@ -431,7 +431,11 @@ class UNetEngine:
             # with an all-zero mask tensor is unmasked; conds of different calls are concatenated row-wise later.
             from .host.attention import visibility_words
             am = grounding.get("att_masks")
-            if am is None or self.pn.eval_drops()[1]:
+            # attention.py:200: unmasked when att_masks is absent, when drop_box_mask = drop_box AND drop_polygons
+            # (text_grounding_net.py:312) or when the whole per-call tensor is zero.  ``att_masks_any`` carries the
+            # per-call ``torch.sum(att_masks) > 0`` decision taken on the UN-sharded batch by a rank-sharding caller.
+            any_flag = grounding.get("att_masks_any")
+            if am is None or self.pn.drop_box_mask or any_flag is False:
                 am = torch.zeros(B, 1, MASK_RES, MASK_RES, device=self.device)
             assert am.shape[-2:] == (MASK_RES, MASK_RES), "the reference masks at the 64x64 resolution only"
             am = am.to(self.device)
@@ -440,7 +444,7 @@ class UNetEngine:
             n_objs = (OBJ_TOKENS - 64) // 4
             if am.shape[1] < n_objs:
                 am = torch.cat([am, torch.zeros(B, n_objs - am.shape[1], MASK_RES, MASK_RES, device=self.device)], 1)
-            c.vis = list(visibility_words(am))
+            c.vis = list(visibility_words(am, force_masked=bool(any_flag) and not self.pn.drop_box_mask))
         ctx16 = ops.cast16(context.to(self.device, torch.float32).contiguous(), ops.empty((B, n_ctx, cd)))
         ld_ctx, ld_obj = _round_up(n_ctx, 64), _round_up(OBJ_TOKENS, 64)
         for p in self._st_layers():

@@ -105,7 +105,7 @@ class SpatialTransformer(nn.Module):
 ALWAYS = -2 ** 31            # bit 31 as an int32: set in every query word and in every unconditionally visible key
 
 
-def visibility_words(att_masks: torch.Tensor, n_groups: int = 4, n_seg_tokens: int = 64):
+def visibility_words(att_masks: torch.Tensor, n_groups: int = 4, n_seg_tokens: int = 64, force_masked: bool = False):
     """The reference's dense [B, 1, N, N] visibility mask of the fuser attention, as 32-bit membership words.
 
     ``att_masks`` [B, n_objs <= 30, h, w] (binary; ``utils/input.py:34-37``).  Visual token i carries one bit per
@@ -118,14 +118,16 @@ def visibility_words(att_masks: torch.Tensor, n_groups: int = 4, n_seg_tokens: i
     attention.py:206-253 for the visual query rows (the only rows attention.py:308 keeps).  The reference decides PER
     CALL whether to mask at all (``torch.sum(att_masks) > 0`` over the whole batch tensor, :200): an all-zero tensor (the
     null grounding input of the unconditional branch) gives all-ones words = no mask; otherwise every sample is masked,
-    and a sample without any instance pixel sees only itself, the point / scribble tokens and the seg tokens."""
+    and a sample without any instance pixel sees only itself, the point / scribble tokens and the seg tokens.
+    ``force_masked``: the caller already took the per-call decision on a LARGER tensor of which ``att_masks`` is a row
+    subset (rank-sharded MIS, host/samplers.py) and it was "masked" -- so mask even if these rows are all zero."""
     B, n_objs = att_masks.shape[0], att_masks.shape[1]
     assert n_objs <= 31, "one bit per instance, bit 31 reserved"
     dev = att_masks.device
     m = (att_masks.reshape(B, n_objs, -1) > 0)
     weights = (torch.ones(n_objs, dtype=torch.int64, device=dev) << torch.arange(n_objs, device=dev)).view(1, n_objs, 1)
     inst = (m.to(torch.int64) * weights).sum(1)                                        # [B, hw], < 2^31
-    unmasked = (~m.any()).expand(B)                                                    # [B], one decision per call
+    unmasked = ((~m.any()) & (not force_masked)).expand(B)                             # [B], one decision per call
     full = torch.full_like(inst, 0xFFFFFFFF)
     q64 = torch.where(unmasked[:, None], full, inst | 0x80000000)
     k64 = torch.where(unmasked[:, None], full, inst)

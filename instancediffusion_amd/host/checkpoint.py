@@ -41,12 +41,30 @@ class _Bag:
         raise pickle.PicklingError("placeholder object")
 
 
+# Globals a reference checkpoint legitimately pickles: tensors / storages (torch), containers (collections, builtins
+# data types), numpy scalars, and the OmegaConf node classes of ``config_dict`` (turned into attribute bags, never
+# imported).  Everything else is refused: a checkpoint is data, it must not be able to name arbitrary callables.
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object"}
+_SAFE_MODULE_ROOTS = ("torch", "collections", "numpy", "typing", "pathlib", "argparse", "enum")
+_BAG_MODULE_ROOTS = ("omegaconf",)
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except (ImportError, AttributeError):
+        root = module.split(".", 1)[0]
+        if root in _BAG_MODULE_ROOTS:
             return type(name, (_Bag,), {"__module__": module})
+        if module == "builtins":
+            if name in _SAFE_BUILTINS:
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"checkpoint names builtins.{name}: refused")
+        if root in _SAFE_MODULE_ROOTS:
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return type(name, (_Bag,), {"__module__": module})
+        raise pickle.UnpicklingError(f"checkpoint names {module}.{name}: refused (not a tensor / container / config class)")
 
 
 class _tolerant_pickle:
@@ -63,11 +81,14 @@ class _tolerant_pickle:
 
 
 def tolerant_torch_load(path: str) -> Dict[str, Any]:
-    """``torch.load(path, map_location='cpu')`` that also works when the file pickles classes of packages that are
-    not installed (OmegaConf in the reference checkpoints).  Only for trusted checkpoints (it unpickles)."""
+    """``torch.load(path, map_location='cpu')`` for the reference's checkpoints without executing what they name:
+    first torch's own ``weights_only`` loader (pure tensor files: the SD-1.5 first-conv file, official SD checkpoints);
+    files that also pickle OmegaConf nodes (``config_dict`` of instancediffusion_sd15.pth) fall back to an allow-listing
+    unpickler (``_TolerantUnpickler``) that turns the OmegaConf classes into attribute bags and refuses every global
+    outside torch / containers / numpy."""
     try:
-        return torch.load(path, map_location="cpu", weights_only=False)
-    except (ModuleNotFoundError, ImportError, AttributeError):
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
         return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle)
 
 
@@ -89,6 +110,22 @@ def plain_config(obj: Any) -> Any:
     if d is not None and "_val" in d:             # AnyNode / StringNode / IntegerNode ... value node
         return plain_config(d["_val"])
     return obj
+
+
+ALLOWED_TARGET_ROOTS = ("ldm", "grounding_input", "instancediffusion_amd")
+
+
+def check_target_namespace(cfg: Any):
+    """Every ``target:`` of a config that came out of a checkpoint must live in this code base's namespaces."""
+    if isinstance(cfg, dict):
+        t = cfg.get("target")
+        if isinstance(t, str) and t.split(".", 1)[0] not in ALLOWED_TARGET_ROOTS:
+            raise ValueError(f"checkpoint config names target {t!r} outside {ALLOWED_TARGET_ROOTS}: refused")
+        for v in cfg.values():
+            check_target_namespace(v)
+    elif isinstance(cfg, (list, tuple)):
+        for v in cfg:
+            check_target_namespace(v)
 
 
 # ---- the reference functions -------------------------------------------------------------------------------------
@@ -120,6 +157,7 @@ def load_model_ckpt(ckpt_path: str, args, device):
         config = plain_config(saved_ckpt["config_dict"])
         if isinstance(config, dict) and "_content" in config:
             config = config["_content"]
+        check_target_namespace(config)              # a checkpoint's own config may only name classes of this code base
 
     model = instantiate_from_config(config["model"]).to(device).eval()
     autoencoder = instantiate_from_config(config["autoencoder"]).to(device).eval()

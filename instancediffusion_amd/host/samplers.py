@@ -232,7 +232,12 @@ class PLMSSamplerInst(_PLMSBase):
             d = dict(inp)
             d["context"] = take(inp["context"])
             if "grounding_input" in inp:
-                d["grounding_input"] = {k: take(v) for k, v in inp["grounding_input"].items()}
+                gin = inp["grounding_input"]
+                d["grounding_input"] = {k: take(v) for k, v in gin.items()}
+                if torch.is_tensor(gin.get("att_masks")) and Bl != B:
+                    # attention.py:200 decides mask / no mask on the WHOLE per-call tensor: take that decision here, on
+                    # the un-sharded batch, so that a rank's row subset cannot flip it (results independent of world)
+                    d["grounding_input"]["att_masks_any"] = bool((gin["att_masks"] > 0).any())
             else:
                 d["grounding_input"] = self.model.grounding_tokenizer_input.get_null_input(batch=Bl)
             return d

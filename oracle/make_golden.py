@@ -348,6 +348,174 @@ def gen_masked_case(tag="tiny_masked_att"):
     torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
 
 
+# ---- f-3: checkpoint loader pin (utils/checkpoint.py:199-249) ---------------------------------------------------------
+CKPT_TEXT_ENCODER = dict(target="torch.nn.Linear", params=dict(in_features=4, out_features=3))
+CKPT_SALTS = dict(model=11, ema=12, autoencoder=7, text_encoder=13)
+
+
+def ckpt_digest(sd):
+    """{key: float64 sum} of a state dict -- small, order-free, sensitive to any swapped / missing tensor."""
+    return {k: float(v.double().sum()) for k, v in sd.items()}
+
+
+@torch.no_grad()
+def gen_ckpt_case(tag="ckpt_tiny"):
+    """``save_ckpt`` -> ``load_model_ckpt`` of the UNMODIFIED reference ``utils/checkpoint.py`` on a reduced-width model
+    set (tiny UNet, tiny VAE, a 4->3 Linear standing in for the CLIP text encoder whose weights cannot be downloaded).
+    Process-local stubs for its un-installable imports (torchvision, omegaconf, tensorboard, dataset.*); ``torch.load``
+    is called the way torch < 2.6 did (weights_only=False), which is what the reference was written against.
+    The golden keeps: the key set of the checkpoint dict the reference's ``save_ckpt`` wrote, per-tensor digests of the
+    modules its ``load_model_ckpt`` returned (ema present / absent; config from the checkpoint / from --test_config),
+    and the returned config."""
+    import importlib
+    import tempfile
+    print(f"[golden] {tag}", flush=True)
+
+    # Minimal stand-ins with OmegaConf's pickled layout: container nodes keep children in ``_content`` (dict / list of
+    # nodes), leaves are value nodes with ``_val``; mapping access unwraps leaves (what the reference code relies on:
+    # ``"target" in cfg``, ``cfg["target"]``, ``cfg.get("params", dict())``, ``**params``).
+    class AnyNode:
+        def __init__(self, val):
+            self.__dict__.update(_metadata=None, _parent=None, _val=val)
+
+    def wrap(v):
+        if isinstance(v, dict):
+            return DictConfig(v)
+        if isinstance(v, (list, tuple)):
+            return ListConfig(v)
+        return AnyNode(v)
+
+    def unwrap(n):
+        return n._val if isinstance(n, AnyNode) else n
+
+    class DictConfig:
+        def __init__(self, content):
+            self.__dict__.update(_metadata=None, _parent=None, _flags_cache=None,
+                                 _content={k: wrap(v) for k, v in content.items()})
+
+        def __contains__(self, k):
+            return k in self._content
+
+        def __getitem__(self, k):
+            return unwrap(self._content[k])
+
+        def get(self, k, default=None):
+            return unwrap(self._content[k]) if k in self._content else default
+
+        def keys(self):
+            return self._content.keys()
+
+        def items(self):
+            return [(k, unwrap(v)) for k, v in self._content.items()]
+
+        def __iter__(self):
+            return iter(self._content)
+
+        def __len__(self):
+            return len(self._content)
+
+    class ListConfig:
+        def __init__(self, content):
+            self.__dict__.update(_metadata=None, _parent=None, _flags_cache=None, _content=[wrap(v) for v in content])
+
+        def __iter__(self):
+            return iter(unwrap(v) for v in self._content)
+
+        def __len__(self):
+            return len(self._content)
+
+        def __getitem__(self, i):
+            return unwrap(self._content[i])
+
+    def to_plain(n):
+        if isinstance(n, DictConfig):
+            return {k: to_plain(v) for k, v in n._content.items()}
+        if isinstance(n, ListConfig):
+            return [to_plain(v) for v in n._content]
+        if isinstance(n, AnyNode):
+            return n._val
+        if isinstance(n, dict):
+            return {k: to_plain(v) for k, v in n.items()}
+        return n
+    for cls, mod in ((DictConfig, "omegaconf.dictconfig"), (ListConfig, "omegaconf.listconfig"), (AnyNode, "omegaconf.nodes")):
+        cls.__module__ = mod
+        cls.__qualname__ = cls.__name__
+    omegaconf = types.ModuleType("omegaconf")
+    oc_dict = types.ModuleType("omegaconf.dictconfig")
+    oc_list = types.ModuleType("omegaconf.listconfig")
+    oc_nodes = types.ModuleType("omegaconf.nodes")
+    oc_dict.DictConfig, oc_list.ListConfig, oc_nodes.AnyNode = DictConfig, ListConfig, AnyNode
+
+    class OmegaConf:
+        @staticmethod
+        def load(path):
+            return DictConfig(yaml.safe_load(open(path)))
+    omegaconf.OmegaConf = OmegaConf
+    omegaconf.DictConfig = DictConfig
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    jd = types.ModuleType("dataset.jsondataset")
+    jd.sub_batch = jd.batch_to_device = None
+    utils_pkg = types.ModuleType("utils")
+    utils_pkg.__path__ = [os.path.join(REF, "utils")]
+    stubs = {"torchvision": types.ModuleType("torchvision"), "omegaconf": omegaconf, "omegaconf.dictconfig": oc_dict,
+             "omegaconf.listconfig": oc_list, "omegaconf.nodes": oc_nodes,
+             "torch.utils.tensorboard": tb, "dataset": types.ModuleType("dataset"), "dataset.jsondataset": jd,
+             "utils": utils_pkg}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    real_load = torch.load
+    torch.load = lambda *a, **k: real_load(*a, **{**k, "weights_only": k.get("weights_only", False) or False})
+    try:
+        ref_ckpt = importlib.import_module("utils.checkpoint")
+        cfg = load_cfg("test_box.yaml", "tiny")
+        cfg["autoencoder"]["params"]["ddconfig"].update(VAE_VARIANTS["tiny"])
+        cfg["text_encoder"] = dict(CKPT_TEXT_ENCODER)
+        model, gi, diffusion, schema, synth = build(cfg, salt=CKPT_SALTS["model"])
+        from ldm.util import instantiate_from_config
+        ae = instantiate_from_config(cfg["autoencoder"]).eval()
+        ae_schema = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+        ae.load_state_dict(synth.synth_state_dict(ae_schema, CKPT_SALTS["autoencoder"]))
+        te = instantiate_from_config(cfg["text_encoder"])
+        te.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in te.state_dict().items()},
+                                                  CKPT_SALTS["text_encoder"]))
+        ema = instantiate_from_config(cfg["model"]).eval()
+        ema.load_state_dict(synth.synth_state_dict(schema, CKPT_SALTS["ema"]))
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda i: 1.0)
+        gold = dict(meta=dict(tag=tag, salts=dict(CKPT_SALTS), text_encoder=dict(CKPT_TEXT_ENCODER)), cases={})
+        for with_ema in (True, False):
+            for use_yaml in (False, True):
+                d = tempfile.mkdtemp()
+                run_cfg = types.SimpleNamespace(distributed=False, enable_ema=with_ema)
+                ref_ckpt.save_ckpt(run_cfg, model, te, ae, opt, sched, vars(DictConfig(cfg)), diffusion, ema, 41, d)   # utils/misc.py:255
+                path = os.path.join(d, "checkpoint_latest.pth")
+                saved_keys = sorted(real_load(path, map_location="cpu", weights_only=False).keys())
+                args = types.SimpleNamespace(test_config="")
+                if use_yaml:
+                    args.test_config = os.path.join(d, "cfg.yaml")
+                    yaml.safe_dump(cfg, open(args.test_config, "w"))
+                m, a, t, df, c = ref_ckpt.load_model_ckpt(path, args, "cpu")
+                gold["cases"][(with_ema, use_yaml)] = dict(
+                    saved_keys=saved_keys, model=ckpt_digest(m.state_dict()), autoencoder=ckpt_digest(a.state_dict()),
+                    text_encoder=ckpt_digest(t.state_dict()), diffusion=ckpt_digest(df.state_dict()),
+                    training=[m.training, a.training, t.training], config=json.loads(json.dumps(to_plain(c))),
+                    config_type=type(c).__name__)
+                os.remove(path)
+        gold["cfg"] = json.loads(json.dumps(cfg))
+        torch.save(gold, os.path.join(GOLD, f"{tag}.pt"))
+        print("[golden] ckpt cases:", list(gold["cases"]))
+    finally:
+        torch.load = real_load
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.modules.pop("utils.checkpoint", None)
+        sys.modules.pop("utils.dist", None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -368,6 +536,18 @@ def main():
     if args.only in ("all", "full"):
         schema = gen_case("full_box_c1", "test_box.yaml", "full", 64, 4, 1, boxes="c1", samplers=False)
         json.dump({k: list(v) for k, v in schema.items()}, open(os.path.join(GOLD, "unet_schema.json"), "w"))
+    if args.only in ("all", "s50"):
+        # BASELINE headline trajectory shape (inference.py:64 steps=50, N=8 instances, mis 0.36) on the reduced variants
+        gen_case("tiny_box_s50", "test_box.yaml", "tiny", 16, 8, 1, alpha_type=(1, 0, 0), S=50, mis=0.36, n_inst=8)
+        gen_case("mid_box_s50", "test_box.yaml", "mid", 16, 8, 1, alpha_type=(0.8, 0.0, 0.2), S=50, mis=0.36, n_inst=8)
+    if args.only in ("all", "c5"):
+        # C5 (point / scribble conditioning): forwards + S=5 PLMS / MIS trajectories
+        gen_case("tiny_point_s5", "test_point.yaml", "tiny", 16, 3, 1, alpha_type=(1, 0, 0))
+        gen_case("tiny_scribble_s5", "test_scribble.yaml", "tiny", 16, 3, 1, with_scribbles=True, with_polygons=True,
+                 with_segs=True, alpha_type=(1, 0, 0))
+    if args.only in ("all", "c4"):
+        # C4 at its stated size: test_mask.yaml, 96x96 latent (768x768), 12 instance masks with segs + polygons
+        gen_case("full_mask_c4", "test_mask.yaml", "full", 96, 12, 1, with_polygons=True, with_segs=True, samplers=False)
     if args.only in ("all", "vae"):
         gen_vae_case("vae_tiny", "tiny", 8, 2)
         schema = gen_vae_case("vae_full_16", "full", 16, 1)
@@ -377,6 +557,8 @@ def main():
         gen_masked_case()
     if args.only in ("all", "input"):
         gen_input_case()
+    if args.only in ("all", "ckpt"):
+        gen_ckpt_case()
     print("done")
 
 

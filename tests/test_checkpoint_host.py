@@ -80,36 +80,88 @@ def _drop_fake_omegaconf():
         sys.modules.pop(k, None)
 
 
-@pytest.mark.parametrize("with_ema,use_yaml", [(True, False), (False, False), (True, True)])
-def test_load_model_ckpt_reference_layout(tmp_path, with_ema, use_yaml):
-    import yaml
-    from utils.checkpoint import load_model_ckpt
-    objs = _build_all()
-    torch.manual_seed(3)
-    sds = {k: {n: torch.randn_like(v) if v.is_floating_point() else v.clone() for n, v in o.state_dict().items()}
-           for k, o in objs.items()}
-    ckpt = dict(model={k: v + 1 for k, v in sds["model"].items()}, autoencoder=sds["autoencoder"],
-                text_encoder=dict(sds["text_encoder"], extra_unexpected=torch.zeros(1)), diffusion=sds["diffusion"],
-                config_dict={"_content": _fake_omegaconf_nodes(TINY)}, iters=123)
-    if with_ema:
-        ckpt["ema"] = sds["model"]
-    path = str(tmp_path / "ckpt.pth")
-    torch.save(ckpt, path)
+def _digest(sd):
+    return {k: float(v.double().sum()) for k, v in sd.items()}
+
+
+def _same_digest(got, want, tol=1e-9):
+    assert sorted(got) == sorted(want)
+    for k, v in want.items():
+        assert abs(got[k] - v) <= tol * max(1.0, abs(v)), (k, got[k], v)
+
+
+@pytest.fixture(scope="module")
+def ref_layout_ckpt(tmp_path_factory):
+    """The reduced checkpoint of the golden case, written ONCE (with and without ``ema``): same key-seeded weights the
+    reference was given, config pickled as OmegaConf-layout nodes in ``vars(cfg)`` form (utils/misc.py:255)."""
+    from instancediffusion_amd import synth
+    from instancediffusion_amd.host.config import instantiate_from_config
+    gold = torch.load(os.path.join(REPO, "tests", "golden", "ckpt_tiny.pt"), weights_only=False)
+    cfg, salts = gold["cfg"], gold["meta"]["salts"]
+    mods = {k: instantiate_from_config(cfg[k]) for k in ("model", "autoencoder", "text_encoder", "diffusion")}
+
+    def synth_sd(mod, salt):
+        return synth.synth_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()}, salt)
+    ckpt = dict(model=synth_sd(mods["model"], salts["model"]), text_encoder=synth_sd(mods["text_encoder"], salts["text_encoder"]),
+                autoencoder=synth_sd(mods["autoencoder"], salts["autoencoder"]), opt={}, scheduler={}, iters=42,
+                config_dict=dict(_metadata=None, _parent=None, _flags_cache=None,
+                                 _content=_fake_omegaconf_nodes(cfg).__dict__["_content"]),
+                diffusion=mods["diffusion"].state_dict(), ema=synth_sd(mods["model"], salts["ema"]))
+    d = tmp_path_factory.mktemp("ckpt")
+    paths = {True: str(d / "with_ema.pth"), False: str(d / "no_ema.pth")}
+    torch.save(ckpt, paths[True])
+    torch.save({k: v for k, v in ckpt.items() if k != "ema"}, paths[False])
     _drop_fake_omegaconf()
+    return gold, ckpt, paths
+
+
+@pytest.mark.parametrize("with_ema,use_yaml", [(True, False), (False, True)])     # the golden also holds the other two
+def test_load_model_ckpt_matches_reference_golden(tmp_path, monkeypatch, ref_layout_ckpt, with_ema, use_yaml):
+    """PIN (tests/golden/ckpt_tiny.pt, oracle/make_golden.py:gen_ckpt_case): the unmodified reference's ``save_ckpt`` wrote
+    a reduced-size checkpoint and its ``load_model_ckpt`` (utils/checkpoint.py:224-249) loaded it; the golden holds the
+    checkpoint's key set, per-tensor digests of the four returned modules and the returned config.  Here the same
+    checkpoint (same key-seeded weights, same key set) goes through the mirror loader, which must return the same
+    5-tuple contents."""
+    import yaml
+    from instancediffusion_amd.host import checkpoint as ck
+    from utils.checkpoint import load_model_ckpt
+    gold, ckpt, paths = ref_layout_ckpt
+    want = gold["cases"][(with_ema, use_yaml)]
+    monkeypatch.setattr(ck, "ALLOWED_TARGET_ROOTS", ck.ALLOWED_TARGET_ROOTS + ("torch",))   # the 4->3 Linear stand-in
+    assert sorted(k for k in ckpt if with_ema or k != "ema") == want["saved_keys"]   # layout the reference's save_ckpt wrote
     args = types.SimpleNamespace(test_config="")
     if use_yaml:
-        ypath = str(tmp_path / "cfg.yaml")
-        yaml.safe_dump(TINY, open(ypath, "w"))
-        args.test_config = ypath
-    model, ae, te, diffusion, config = load_model_ckpt(path, args, "cpu")
-    want = sds["model"] if with_ema else ckpt["model"]
-    got = model.state_dict()
-    assert all(torch.equal(got[k], want[k]) for k in want)
-    assert all(torch.equal(ae.state_dict()[k], v) for k, v in sds["autoencoder"].items())
-    assert torch.equal(te.w, sds["text_encoder"]["w"]) and not model.training and not ae.training
-    assert torch.equal(diffusion.betas, sds["diffusion"]["betas"])
-    assert config["model"]["params"]["model_channels"] == 64 and isinstance(config["model"], dict)
+        args.test_config = str(tmp_path / "cfg.yaml")
+        yaml.safe_dump(gold["cfg"], open(args.test_config, "w"))
+    model, ae, te, diffusion, config = load_model_ckpt(paths[with_ema], args, "cpu")
+    _same_digest(_digest(model.state_dict()), want["model"])
+    _same_digest(_digest(ae.state_dict()), want["autoencoder"])
+    _same_digest(_digest(te.state_dict()), want["text_encoder"])
+    _same_digest(_digest(diffusion.state_dict()), want["diffusion"], tol=1e-6)
+    assert [model.training, ae.training, te.training] == want["training"]
+    assert config == want["config"]
+    # ema present -> ema weights; absent -> model weights (the bare-except fallback of the reference)
+    src = ckpt["ema"] if with_ema else ckpt["model"]
+    assert all(torch.equal(model.state_dict()[k], v) for k, v in src.items())
     assert type(model).__module__.startswith("instancediffusion_amd") and type(ae).__module__.startswith("instancediffusion_amd")
+
+
+def test_checkpoint_loading_refuses_foreign_globals_and_targets(tmp_path):
+    """A checkpoint is data: pickled globals outside torch / containers / numpy / (bagged) omegaconf are refused, and a
+    checkpoint-embedded config may only name classes of this code base."""
+    import pickle
+    from instancediffusion_amd.host import checkpoint as ck
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    path = str(tmp_path / "evil.pth")
+    torch.save(dict(model={}, payload=Evil()), path)
+    with pytest.raises(pickle.UnpicklingError):
+        ck.tolerant_torch_load(path)
+    with pytest.raises(ValueError):
+        ck.check_target_namespace(dict(model=dict(target="os.system", params={})))
+    ck.check_target_namespace(dict(model=dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel")))
 
 
 def test_read_official_ckpt_split(tmp_path):

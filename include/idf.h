@@ -50,7 +50,9 @@ const char* idf_build_info(void);
  *   stages), 1 = two independent 4-wave workgroups per CU on 128-row tiles (32-deep K-tiles, 3 / 2 stages).  Env IDF_GEMM_GEOM.
  *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; otherwise, when the shape qualifies, the
  *   64-queries-per-wave LDS-DMA kernel: 1 = classic online softmax, 2 = software-pipelined form (softmax of one query
- *   group beside the MFMAs of the other), 3 = lazy rescaling (default: fastest), 4 = pipelined + lazy (d in {24,40,56}, n0 % 8 == n1 % 8 == 0).  Initial value: env IDF_ATTN2 or default. */
+ *   group beside the MFMAs of the other), 3 = lazy rescaling, 4 = pipelined + lazy (d in {24,40,56}, n0 % 8 == n1 % 8 == 0); 5 = variant 4 (attention4.hip: max-free
+ *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid),
+ *   6 = variant 4 with the plain block order (A/B of the XCD mapping).  Initial value: env IDF_ATTN2 or default. */
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_GEOM = 2 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */

@@ -28,3 +28,6 @@ extern long long idf_stat_attn2_launches;
 int idf_attn2_mode();
 int idf_attn2_set_mode(int v);
 int idf_launch_attn2(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
+// variant 4 (attention4.hip): max-free softmax with the reference value folded into the K.Q^T MFMA, K fragments read one
+// tile ahead, XCD-aware 1-D grid.  Selected by attention mode 5; same IDF_ATTN2_UNSUPPORTED contract.
+int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);

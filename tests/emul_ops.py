@@ -19,6 +19,7 @@ class EmulOps:
         self.dtype = dtype
         self.device = torch.device("cpu")
         self.calls = {}
+        self.rows = {}            # batch rows that went through an op (work measure: launches x batch)
 
     def _count(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1
@@ -91,6 +92,7 @@ class EmulOps:
 
     def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0, qbits=None, kbits0=None, kbits1=None):
         self._count("attention")
+        self.rows["attention"] = self.rows.get("attention", 0) + int(q.shape[0])
         if qbits is not None:
             self._count("attention_masked")
         B, Nq, C = q.shape

@@ -1,15 +1,33 @@
 """End-to-end parity of the HIP UNet engine on a real MI355X against (a) golden outputs of the unmodified
 reference and (b) the live CPU oracle, on the same seeded weights/inputs.
 
-Stated tolerance (anchored on the reference's own bf16-autocast noise floor of 1.55e-2 rel-RMS):
-bf16 storage / fp32 accumulate, per UNet forward: rel-RMS <= 3e-2 and max-abs <= 0.15 * RMS(eps).
+Stated tolerance: per UNet forward rel-RMS <= 2e-2 (bf16) / 3e-3 (fp16) and max-abs / RMS(eps) <= 1e-1 /
+1.5e-2 -- bars that SURVEY anchored on the reference's own autocast noise floor for the C1 inputs.  That floor was since
+measured for EVERY golden case (oracle/noise_floor.py -> tests/golden/noise_floor.json: the unmodified reference under
+torch.autocast vs its own fp32 output, 1.75e-2 .. 2.3e-2 in bf16, 2.1e-3 .. 2.8e-3 in fp16); where 1.25 x the case's own
+floor exceeds the SURVEY bar (the reduced-width "tiny" variants), that is the tolerance -- the engine is then still held to
+the precision the reference itself delivers at that storage type.  Both numbers are printed with every result.
 """
+import json
+import os
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = 3e-2
+SURVEY_BAR = {"bf16": (2e-2, 1e-1), "fp16": (3e-3, 1.5e-2)}
+_FLOOR = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise_floor.json")))
+_FLOOR_ALIAS = {"tiny_point_s5": "tiny_point", "tiny_scribble_s5": "tiny_scribble"}
+
+
+def fwd_tol(tag, dtype="bf16"):
+    """(rel-RMS tolerance, max-abs/RMS tolerance, the reference's own floor) for a golden case."""
+    bar_rms, bar_max = SURVEY_BAR[dtype]
+    f = _FLOOR.get(_FLOOR_ALIAS.get(tag, tag))
+    if f is None or f.get(dtype) is None:
+        return bar_rms, bar_max, None
+    return max(bar_rms, 1.25 * f[dtype]), max(bar_max, 1.25 * f[dtype + "_maxabs_over_rms"]), f[dtype]
 
 
 def _build(cfg):
@@ -25,15 +43,17 @@ def _case(tag):
     return gold, meta, cfg, cases.build_inputs(meta)
 
 
-def _check(eps, want, what):
+def _check(eps, want, what, tag=None, dtype="bf16"):
     from tests import cases
     eps = eps.float().cpu()
     err = cases.rel_rms(eps, want)
     mx = float((eps - want).abs().max() / want.pow(2).mean().sqrt())
-    print(f"[parity] {what}: rel-rms {err:.3e}  max-abs/rms {mx:.3e}")
+    tol, tol_max, floor = fwd_tol(tag, dtype)
+    print(f"[parity] {what} [{dtype}]: rel-rms {err:.3e} (tol {tol:.2e}, reference's own {dtype} floor "
+          f"{'n/a' if floor is None else format(floor, '.2e')})  max-abs/rms {mx:.3e} (tol {tol_max:.2e})")
     assert torch.isfinite(eps).all(), what
-    assert err < FWD_TOL, f"{what}: rel-rms {err}"
-    assert mx < 0.15, f"{what}: max-abs/rms {mx}"
+    assert err < tol, f"{what}: rel-rms {err}"
+    assert mx < tol_max, f"{what}: max-abs/rms {mx}"
 
 
 @pytest.mark.parametrize("tag", ["tiny_box", "tiny_point", "mid_box", "tiny_mask", "tiny_scribble"])
@@ -48,17 +68,17 @@ def test_forward_matches_reference_golden(tag):
     with torch.no_grad():
         # reference-style entry point: model(input dict)
         eps = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
-        _check(eps, gold["eps_cond"], f"{tag} cond")
+        _check(eps, gold["eps_cond"], f"{tag} cond", tag)
         eps2 = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
         assert torch.equal(eps, eps2), "graph replay must be bitwise identical to the eager warm-up"
         eps_u = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["uc"].cuda()))
-        _check(eps_u, gold["eps_uncond"], f"{tag} uncond (null grounding)")
+        _check(eps_u, gold["eps_uncond"], f"{tag} uncond (null grounding)", tag)
         from ldm.modules.attention import GatedSelfAttentionDense
         for m in model.modules():
             if type(m) == GatedSelfAttentionDense:
                 m.scale = 0.3
         eps_s = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
-        _check(eps_s, gold["eps_scale03"], f"{tag} fuser scale 0.3")
+        _check(eps_s, gold["eps_scale03"], f"{tag} fuser scale 0.3", tag)
 
 
 def test_full_size_forward_matches_reference_golden():
@@ -71,7 +91,26 @@ def test_full_size_forward_matches_reference_golden():
     g = {k: v.cuda() for k, v in gi.prepare(inp["gb"]).items()}
     with torch.no_grad():
         eps = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
-    _check(eps, gold["eps_cond"], "full C1 cond")
+    _check(eps, gold["eps_cond"], "full C1 cond", "full_box_c1")
+
+
+def test_full_size_c4_forward_matches_reference_golden():
+    """BASELINE config 4 at its stated size: configs/test_mask.yaml, 96x96 latent (768x768), 12 instance masks with segs
+    + polygons (ConvNeXt mask tokens live), the full 1.228 B-parameter model; non-power-of-two planes at every level
+    (96 / 48 / 24 / 12), 9216 + 184 keys in the 96^2 attention."""
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    gold, meta, cfg, inp = _case("full_mask_c4")
+    assert meta["latent"] == 96 and meta["n_boxes"] == 12
+    model = _build(cfg)
+    gi = GroundingNetInput()
+    model.grounding_tokenizer_input = gi
+    g = {k: v.cuda() for k, v in gi.prepare(inp["gb"]).items()}
+    gi.prepare({k: v.cuda() for k, v in inp["gb"].items()})
+    with torch.no_grad():
+        eps = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
+        _check(eps, gold["eps_cond"], "full C4 (96^2, 12 masks) cond", "full_mask_c4")
+        eps_u = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["uc"].cuda()))
+        _check(eps_u, gold["eps_uncond"], "full C4 uncond (null grounding)", "full_mask_c4")
 
 
 def test_forward_matches_live_oracle_other_timestep_and_batch():
@@ -98,25 +137,26 @@ def test_forward_matches_live_oracle_other_timestep_and_batch():
             eng.set_fuser_scale(scale)
             cond = eng.prepare_cond(ctx.cuda(), {k: v.cuda() for k, v in grounding.items()})
             eps = eng.forward_cond(x.cuda(), t.cuda(), cond)
-            _check(eps, want, f"mid live-oracle scale={scale}")
+            _check(eps, want, f"mid live-oracle scale={scale}", "mid_box")
 
 
-def test_fp16_forward_matches_reference_golden():
+@pytest.mark.parametrize("tag", ["mid_box", "tiny_point", "tiny_scribble", "tiny_mask"])
+def test_fp16_forward_matches_reference_golden(tag):
     """C5 dtype: the same kernels instantiated for fp16 storage / fp16 MFMA (the reference's own GPU path is fp16
-    autocast, inference.py:94).  Stated tolerance: rel-RMS <= 5e-3 (reference fp16-autocast noise floor 1.9e-3)."""
+    autocast, inference.py:94), on the point and scribble configurations (C5) plus box and mask."""
     from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
-    from tests import cases
-    gold, meta, cfg, inp = _case("mid_box")
+    gold, meta, cfg, inp = _case(tag)
     model = _build(cfg)
     model.compute_dtype = torch.float16
     gi = GroundingNetInput()
     model.grounding_tokenizer_input = gi
     g = {k: v.cuda() for k, v in gi.prepare(inp["gb"]).items()}
+    gi.prepare({k: v.cuda() for k, v in inp["gb"].items()})
     with torch.no_grad():
         eps = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["context"].cuda(), grounding_input=g))
-    err = cases.rel_rms(eps.float().cpu(), gold["eps_cond"])
-    print(f"[parity] mid_box fp16 cond: rel-rms {err:.3e}")
-    assert torch.isfinite(eps).all() and err < 5e-3
+        _check(eps, gold["eps_cond"], f"{tag} fp16 cond", tag, "fp16")
+        eps_u = model(dict(x=inp["x"].cuda(), timesteps=inp["t"].cuda(), context=inp["uc"].cuda()))
+        _check(eps_u, gold["eps_uncond"], f"{tag} fp16 uncond (null grounding)", tag, "fp16")
 
 
 def test_non_power_of_two_latent_matches_live_oracle():
@@ -146,4 +186,4 @@ def test_non_power_of_two_latent_matches_live_oracle():
         print(f"[parity] UniFusion tokens (incl. ConvNeXt mask tokens) rel-rms {tok_err:.3e}")
         assert tok_err < 2e-2
         eps = eng.forward_cond(x.cuda(), t.cuda(), cond)
-    _check(eps, want, "mid test_mask 48x48 latent, live oracle")
+    _check(eps, want, "mid test_mask 48x48 latent, live oracle", "mid_box")

@@ -475,7 +475,7 @@ def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
 # ---------------------------------------------------------------------------------------------------
 # attention variant 2 (attention2.hip: 64 queries per wave, LDS-DMA staging), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4], ids=["v2", "v3-pipelined", "v2-lazy", "v3-pipelined-lazy"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6], ids=["v2", "v3-pipelined", "v2-lazy", "v3-pipelined-lazy", "v4", "v4-plain-grid"])
 def attn2(request):
     from instancediffusion_amd import _lib
     lib = _lib.load()
@@ -544,6 +544,64 @@ def test_attention_v2_matches_v1(ops, attn2):
     _lib.load().idf_set_tuning(1, mode)
     assert attn2() == 1
     assert relmax(o2, o1) < BF16_TOL
+
+
+def rel_rms(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float(((a - b).pow(2).mean() / b.pow(2).mean().clamp_min(1e-30)).sqrt())
+
+
+@pytest.fixture(params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def attn4(request):
+    """Variant 4 (attention4.hip) forced through idf_set_tuning, in both storage types."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.ops import HipOps
+    lib = _lib.load()
+    prev = lib.idf_set_tuning(1, 5)
+    start = lib.idf_get_stat(1)
+    yield HipOps(request.param), request.param, (lambda: lib.idf_get_stat(1) - start)
+    lib.idf_set_tuning(1, prev)
+
+
+@pytest.mark.parametrize("case", ["plain", "late-spike", "first-tile-spike", "overflow", "tail-only", "seg1-spike"])
+def test_attention_v4_reference_value_paths(ref, attn4, case):
+    """The max-free softmax of variant 4: the reference value m is fixed on the first tile and only raised when a packed P
+    reaches 2.  Exercise (a) the common path, (b) a finite late spike (m raised from the packed P, O rescaled), (c) a spike
+    in the first tile (later P underflow, never raised), (d) a spike that overflows P to inf (the workgroup redoes the
+    block with the exact per-tile max), (e) n0 < 64 (the first tile is a tail tile) and (f) a spike inside the tail tile
+    of segment 1.  Checked against the fp32 reference in rel-RMS AND relative to the output max."""
+    ops, dt, count = attn4
+    B, H, d, N, n1 = 2, 8, 40, 640, 184
+    if case == "tail-only":
+        N = 40
+    C = H * d
+    q, k, v = gen((B, N, C), 60), gen((B, N, C), 61), gen((B, N, C), 62)
+    k1, v1 = gen((B, n1, C), 63), gen((B, n1, C), 64)
+    if case == "late-spike":
+        k[:, 500] = q[:, 7] * 4.0                       # ~ +36 in log2 units for query 7 at key 500 (8th tile)
+    if case == "first-tile-spike":
+        k[:, 3] = q[:, 300] * 6.0
+    if case == "overflow":
+        k[:, 450] = q[:, 9] * 40.0                      # ~ +360 in log2 units: P = inf in bf16 and fp16
+        k[0, 130] = q[0, 100] * 25.0
+    if case == "seg1-spike":
+        k1[:, 180] = q[:, 11] * 5.0                     # inside the 56-key tail tile of the grounding segment
+    q, k, v, k1, v1 = (t.to(dt) for t in (q, k, v, k1, v1))
+    ld0 = (N + 63) // 64 * 64
+    vt = torch.full((B, C, ld0), float("nan"), dtype=dt)
+    vt[:, :, :N] = v.transpose(1, 2)
+    vt1 = torch.full((B, C, 192), float("nan"), dtype=dt)
+    vt1[:, :, :n1] = v1.transpose(1, 2)
+    want = ref.attention(q.float(), k.float(), torch.nan_to_num(vt.float()), N, torch.empty(B, N, C), H,
+                         k1=k1.float(), vt1=torch.nan_to_num(vt1.float()), n1=n1)
+    out = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H, k1=dev(k1), vt1=dev(vt1), n1=n1)
+    torch.cuda.synchronize()
+    assert count() == 1
+    assert torch.isfinite(out.float()).all()
+    tol = BF16_TOL if dt == torch.bfloat16 else 2.0 ** -10
+    err, mx = rel_rms(out, want), relmax(out, want)
+    print(f"[parity] attention v4 {case} {dt}: rel-rms {err:.3e} max-rel {mx:.3e}")
+    assert mx < 2 * tol and err < tol
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,8 +1,9 @@
 """Sampler parity on a real MI355X: PLMSSampler / PLMSSamplerInst (HIP engine, hipGraph replay, batched CFG and
 batched MIS trajectories) vs the unmodified reference's trajectories (goldens).
 
-Stated tolerance: bf16 storage, CFG 7.5 amplifies per-forward eps noise (~1.5e-2 rel-RMS) -> per-trajectory latent
-rel-RMS <= 8e-2 on these 5-step / 4-step trajectories (CPU bf16 emulation of the same engine gives 2.4e-2..4.2e-2).
+Stated tolerance: per-trajectory latent rel-RMS <= 5e-2 in bf16, <= 1e-2 in fp16 -- for the short (S = 4 / 5)
+trajectories AND for the headline shape: S = 50 PLMS steps (inference.py:64), N = 8 instances, MIS 0.36, CFG 7.5, where 406
+forwards are chained per image.  Every test prints its measured value ("[parity] ..." lines, kept under profiles/).
 """
 from functools import partial
 
@@ -10,10 +11,10 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-TRAJ_TOL = 8e-2
+TRAJ_TOL = {torch.bfloat16: 5e-2, torch.float16: 1e-2}
 
 
-def _setup(tag):
+def _setup(tag, dtype=torch.bfloat16):
     from instancediffusion_amd import synth
     from instancediffusion_amd.host.diffusion import LatentDiffusion
     from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
@@ -24,6 +25,7 @@ def _setup(tag):
     cfg = cases.cfg_for(meta["cfg"], meta["variant"])
     inp = cases.build_inputs(meta)
     model = build_model(cfg)
+    model.compute_dtype = dtype
     model.first_conv_sd_override = synth.synth_first_conv_sd()
     gi = GroundingNetInput()
     model.grounding_tokenizer_input = gi
@@ -35,34 +37,108 @@ def _cuda(d):
     return {k: v.cuda() for k, v in d.items()}
 
 
-@pytest.mark.parametrize("tag", ["tiny_box", "mid_box"])
-def test_plms_and_mis_match_reference(tag):
-    from instancediffusion_amd import synth
+def _run_plms(tag, dtype):
     from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
-    from instancediffusion_amd.host.samplers import PLMSSampler, PLMSSamplerInst
+    from instancediffusion_amd.host.samplers import PLMSSampler
     from tests import cases
-    gold, meta, inp, model, gi, diffusion = _setup(tag)
+    gold, meta, inp, model, gi, diffusion = _setup(tag, dtype)
     ag = partial(alpha_generator, type=meta["alpha_type"])
     shape = tuple(inp["x"].shape)
     sampler = PLMSSampler(diffusion, model, alpha_generator_func=ag, set_alpha_scale=set_alpha_scale)
     i0 = dict(x=inp["x"].cuda(), timesteps=None, context=inp["context"].cuda(), grounding_input=gi.prepare(_cuda(inp["gb"])))
     out = sampler.sample(S=meta["S"], shape=shape, input=i0, uc=inp["uc"].cuda(), guidance_scale=7.5)
     err = cases.rel_rms(out.cpu(), gold["plms"])
-    print(f"[parity] {tag} PLMS S={meta['S']} CFG7.5 latent rel-rms {err:.3e}")
-    assert torch.isfinite(out).all() and err < TRAJ_TOL
+    print(f"[parity] {tag} PLMS S={meta['S']} CFG7.5 {dtype}: latent rel-rms {err:.3e} (tol {TRAJ_TOL[dtype]:.0e})")
+    assert torch.isfinite(out).all() and err < TRAJ_TOL[dtype]
 
-    gold, meta, inp, model, gi, diffusion = _setup(tag)
-    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=ag, set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+
+def _mis_inputs(inp, gi, meta):
+    from instancediffusion_amd import synth
     inputs = [dict(x=inp["x"].cuda(), timesteps=None, context=inp["context"].cuda(), grounding_input=gi.prepare(_cuda(inp["gb"])))]
     for i in range(meta["n_inst"]):
         inputs.append(dict(x=inp["x"].cuda(), timesteps=None, context=inp["inst_ctx"][i].cuda(),
                            grounding_input=gi.prepare(_cuda(synth.instance_batch(inp["gb"], i)))))
     gi.prepare(_cuda(inp["gb"]))
+    return inputs
+
+
+def _run_mis(tag, dtype, second_call=False):
+    from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.samplers import PLMSSamplerInst
+    from tests import cases
+    gold, meta, inp, model, gi, diffusion = _setup(tag, dtype)
+    ag = partial(alpha_generator, type=meta["alpha_type"])
+    shape = tuple(inp["x"].shape)
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=ag, set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+    inputs = _mis_inputs(inp, gi, meta)
     out = sampler.sample(S=meta["S"], shape=shape, input=inputs, uc=inp["uc"].cuda(), guidance_scale=7.5)
     err = cases.rel_rms(out.cpu(), gold["mis"])
-    print(f"[parity] {tag} MIS S={meta['S']} mis={meta['mis']} latent rel-rms {err:.3e}")
-    assert torch.isfinite(out).all() and err < TRAJ_TOL
-    out2 = sampler.sample(S=meta["S"], shape=shape, input=[dict(d, x=inp["x"].cuda()) for d in inputs],
-                          uc=inp["uc"].cuda(), guidance_scale=7.5)
-    # second call: first conv stays swapped (reference quirk) -> not comparable to the golden, but must be finite
-    assert torch.isfinite(out2).all()
+    print(f"[parity] {tag} MIS S={meta['S']} mis={meta['mis']} N={meta['n_inst']} {dtype}: latent rel-rms {err:.3e} "
+          f"(tol {TRAJ_TOL[dtype]:.0e})")
+    assert torch.isfinite(out).all() and err < TRAJ_TOL[dtype]
+    if second_call:
+        out2 = sampler.sample(S=meta["S"], shape=shape, input=[dict(d, x=inp["x"].cuda()) for d in inputs],
+                              uc=inp["uc"].cuda(), guidance_scale=7.5)
+        # second call: first conv stays swapped (reference quirk) -> not comparable to the golden, but must be finite
+        assert torch.isfinite(out2).all()
+
+
+@pytest.mark.parametrize("tag", ["tiny_box", "mid_box"])
+def test_plms_and_mis_match_reference(tag):
+    _run_plms(tag, torch.bfloat16)
+    _run_mis(tag, torch.bfloat16, second_call=True)
+
+
+@pytest.mark.parametrize("tag", ["tiny_box_s50", "mid_box_s50"])
+def test_headline_trajectory_s50_n8_matches_reference(tag):
+    """The BASELINE trajectory shape: S = 50, N = 8 instances, mis 0.36 (mis_step 18), CFG 7.5 -- 406 chained forwards per
+    image; ``mid_box_s50`` (the real 320 / 640 / 1280 widths, head dims 40 / 80 / 160) also runs the alpha schedule
+    [0.8, 0, 0.2] with the first-conv swap at step 40.  Goldens: the unmodified reference on the same seeds."""
+    _run_plms(tag, torch.bfloat16)
+    _run_mis(tag, torch.bfloat16)
+
+
+@pytest.mark.parametrize("tag", ["mid_box_s50"])
+def test_headline_trajectory_s50_n8_fp16(tag):
+    """Same, in the reference's own GPU storage type (fp16 autocast, inference.py:94)."""
+    _run_plms(tag, torch.float16)
+    _run_mis(tag, torch.float16)
+
+
+@pytest.mark.parametrize("tag", ["tiny_point_s5", "tiny_scribble_s5"])
+def test_c5_point_scribble_samplers_fp16(tag):
+    """BASELINE config 5: point / scribble conditioning, fp16, PLMS and MIS trajectories (S = 5)."""
+    _run_plms(tag, torch.float16)
+    _run_mis(tag, torch.float16)
+
+
+def test_mis_crop_and_paste_on_gpu_vs_oracle():
+    """The opt-in crop-and-paste merge (plms_instance.py:112-132, hard-coded off in the reference :128) through the HIP
+    sampler (``idf_mis_merge`` mode 1, the reference's index order) against the CPU oracle run live on the same seeds."""
+    from instancediffusion_amd import synth
+    from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.samplers import PLMSSamplerInst
+    from oracle import ref_cpu
+    from tests import cases
+    gold, meta, inp, model, gi, diffusion = _setup("tiny_box")
+    S, mis, at = 5, 0.4, meta["alpha_type"]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = cases.cfg_for(meta["cfg"], meta["variant"])
+    with torch.no_grad():
+        om = ref_cpu.OracleModel(sd, cfg, synth.synth_first_conv_sd())
+        g0 = ref_cpu.prepare_grounding(inp["gb"])
+        oin = [dict(x=inp["x"].clone(), timesteps=None, context=inp["context"], grounding_input=g0)]
+        for i in range(meta["n_inst"]):
+            oin.append(dict(x=inp["x"].clone(), timesteps=None, context=inp["inst_ctx"][i],
+                            grounding_input=ref_cpu.prepare_grounding(synth.instance_batch(inp["gb"], i))))
+        want = ref_cpu.plms_sample_mis(om, S, oin, inp["uc"], 7.5, mis, alpha_type=at, crop_and_paste=True)
+        plain = ref_cpu.plms_sample_mis(ref_cpu.OracleModel(sd, cfg, synth.synth_first_conv_sd()), S,
+                                        [dict(d, x=inp["x"].clone()) for d in oin], inp["uc"], 7.5, mis, alpha_type=at)
+    assert cases.rel_rms(want, plain) > 1e-2, "the two merge modes must differ on this case for the test to mean anything"
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=at),
+                              set_alpha_scale=set_alpha_scale, mis=mis, crop_and_paste_latents=True)
+    out = sampler.sample(S=S, shape=tuple(inp["x"].shape), input=_mis_inputs(inp, gi, meta), uc=inp["uc"].cuda(),
+                         guidance_scale=7.5)
+    err = cases.rel_rms(out.cpu(), want)
+    print(f"[parity] tiny_box MIS crop-and-paste S={S}: latent rel-rms {err:.3e} (tol {TRAJ_TOL[torch.bfloat16]:.0e})")
+    assert torch.isfinite(out).all() and err < TRAJ_TOL[torch.bfloat16]

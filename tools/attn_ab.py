@@ -1,0 +1,67 @@
+"""A/B of the attention variants on the headline shapes (MI355X box): python tools/attn_ab.py [batch=64] [modes=3,5,6]
+Prints TFLOP/s per (shape, mode); mode = IDF_TUNE_ATTN2 value (0 = 32-query kernel, 3 = variant 2 lazy, 5 = variant 4)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from instancediffusion_amd import _lib  # noqa: E402
+from instancediffusion_amd.ops import HipOps  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+modes = [int(m) for m in (sys.argv[2] if len(sys.argv) > 2 else "3,5,6").split(",")]
+dt = torch.float16 if os.environ.get("ATTN_AB_DTYPE") == "fp16" else torch.bfloat16
+ops = HipOps(dt)
+lib = _lib.load()
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def rnd(*shape):
+    return (torch.randn(*shape, device="cuda") * 0.5).to(dt)
+
+
+res = []
+for (N, d, n1, tag) in [(4096, 40, 0, "self 64^2"), (4096, 40, 184, "gated 64^2"), (1024, 80, 184, "gated 32^2"),
+                        (256, 160, 184, "gated 16^2"), (4096, 40, -77, "cross 64^2"), (9216, 40, 184, "gated 96^2 (C4)")]:
+    Bx = B if N <= 4096 else max(1, B // 4)
+    C = 8 * d
+    # q / k as column slices of the fused projection buffer, V^T in the batch-interleaved image -- as the engine calls it
+    qk = rnd(Bx, N, 2 * C)
+    q = qk[:, :, :C]
+    if n1 < 0:
+        n0, k0, vt0, n1 = 77, rnd(Bx, 77, C), torch.zeros(Bx, C, 128, device="cuda", dtype=dt), 0
+    else:
+        n0, k0 = N, qk[:, :, C:]
+        vt0 = rnd(C, Bx, N).permute(1, 0, 2)
+    o = ops.empty((Bx, N, C))
+    kw = dict(k1=rnd(Bx, 184, C), vt1=rnd(Bx, C, 192), n1=184) if n1 else {}
+    flops = 4.0 * Bx * N * (n0 + n1) * C
+    outs = {}
+    for m in modes:
+        prev = lib.idf_set_tuning(1, m)
+        sec = timeit(lambda: ops.attention(q, k0, vt0, n0, o, 8, **kw))
+        outs[m] = o.float().clone()
+        lib.idf_set_tuning(1, prev)
+        r = dict(shape=tag, B=Bx, d=d, mode=m, us=round(sec * 1e6, 1), tflops=round(flops / sec / 1e12, 1),
+                 frac_mfma=round(flops / sec / 2.5e15, 4))
+        if m != modes[0]:
+            a, b = outs[m], outs[modes[0]]
+            r["relrms_vs_mode%d" % modes[0]] = float(((a - b).pow(2).mean() / b.pow(2).mean()).sqrt())
+        res.append(r)
+        print(json.dumps(r), flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open(f"gpurun_out/attn_ab_B{B}.json", "w"), indent=1)

@@ -52,7 +52,10 @@ const char* idf_build_info(void);
  *   64-queries-per-wave LDS-DMA kernel: 1 = classic online softmax, 2 = software-pipelined form (softmax of one query
  *   group beside the MFMAs of the other), 3 = lazy rescaling, 4 = pipelined + lazy (d in {24,40,56}, n0 % 8 == n1 % 8 == 0); 5 = variant 4 (attention4.hip: max-free
  *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid),
- *   6 = variant 4 with the plain block order (A/B of the XCD mapping).  Initial value: env IDF_ATTN2 or default. */
+ *   6 = variant 4 with the plain block order (A/B of the XCD mapping), 7 / 8 = variant 4 with V^T fetched two tiles ahead;
+ *   9 = variant 5 (attention5.hip: variant 4 as one 8-wave workgroup per 512 queries whose two waves per SIMD alternate
+ *   between a matrix phase and a scalar phase), 10 = variant 5 with the plain block order, 11 = variant 5 with s_setprio 1
+ *   in the matrix phases.  Initial value: env IDF_ATTN2 or default. */
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_GEOM = 2 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */

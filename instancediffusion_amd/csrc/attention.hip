@@ -362,6 +362,10 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
     p.kbits[1] = (const unsigned*)(a->n1 > 0 ? a->kbits1 : a->kbits0); p.sKb[1] = a->n1 > 0 ? a->strideKb1 : a->strideKb0;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (!a->qbits && idf_attn2_mode() >= 9) {
+    const int rc = idf_launch_attn5(p, a->B, a->dtype, s);
+    if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }
+  }
   if (!a->qbits && idf_attn2_mode() >= 5) {
     const int rc = idf_launch_attn4(p, a->B, a->dtype, s);
     if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }

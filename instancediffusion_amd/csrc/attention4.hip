@@ -50,9 +50,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // lds = LDS byte address of lane 0's 16-B slot (lane i lands at lds + 16 i); it goes through M0.
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
 __device__ __forceinline__ void dma16_sv(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);         // wave-uniform by construction; make it provably so (an SGPR for M0)
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");   // M0 is ours here: nothing else in this kernel uses it (no movrel / GWS / sendmsg)
 }
 __device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(addr) : "memory");   // M0 is ours here: nothing else in this kernel uses it (no movrel / GWS / sendmsg)
 }
 
@@ -63,7 +65,9 @@ template <int DT> struct RefShift;           // after a re-base the largest P of
 template <> struct RefShift<IDF_BF16> { static constexpr float v = 7.0f; };    // bf16: 8 exponent bits, shift is free
 template <> struct RefShift<IDF_F16> { static constexpr float v = 1.0f; };     // fp16: keep P near the top of its range
 
-template <int DT, int NKS, int NMT>
+// VA = how many tiles ahead V^T is fetched (1: 2-stage ring, wait for everything at the end of a tile; 2: 3-stage ring like K,
+// and the end-of-tile wait leaves the loads issued in THIS tile in flight -- they have two tiles to land).
+template <int DT, int NKS, int NMT, int VA>
 __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const int nqb, const int xcd_order) {
   constexpr int DCH = 2 * NKS - 1;                 // 16-B chunks per K row
   constexpr int D = 8 * DCH;                       // head dim
@@ -74,11 +78,12 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   constexpr int V_INST = D / 8;                    // per V^T tile (8 rows each); instruction V_INST = the ones-row group
   constexpr int K_PER_WAVE = (K_INST + 3) / 4, V_PER_WAVE = (V_INST + 3) / 4;
   static_assert(D < 32 * NMT && (D % 8) == 0 && D + 8 <= VROWS, "needs a spare 8-row group for the softmax denominator");
-  __shared__ __attribute__((aligned(128))) unsigned short smem[3 * KSZ + 2 * VSZ + 8];
+  constexpr int VST = VA + 1;                      // V^T ring stages
+  __shared__ __attribute__((aligned(128))) unsigned short smem[3 * KSZ + VST * VSZ + 8];
   __shared__ int redo_flag;                        // some wave met an inf / nan P: redo the block with the exact per-tile max
   unsigned short* const Ks = smem;
   unsigned short* const Vs = smem + 3 * KSZ;
-  unsigned short* const ones_frag = smem + 3 * KSZ + 2 * VSZ;
+  unsigned short* const ones_frag = smem + 3 * KSZ + VST * VSZ;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
@@ -94,11 +99,11 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   const int b = L / (nqb * p.H);
 
   // zero the V^T ring once (pad rows of the O^T tile must be finite zeros), then the ones row and the ones fragment
-  for (int i = tid; i < VSZ; i += 256) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
+  for (int i = tid; i < VST * VSZ / 2; i += 256) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
   __syncthreads();
   {
     const unsigned short one = Elem<DT>::from_f32(1.0f);
-    for (int i = tid; i < 2 * KVT; i += 256) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
+    for (int i = tid; i < VST * KVT; i += 256) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
     if (tid < 8) ones_frag[tid] = tid == 0 ? one : (unsigned short)0;
     if (tid == 0) redo_flag = 0;
   }
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
     const char* vb = seg ? vbase1 : vbase0;
-    unsigned short* dst = Vs + (t & 1) * VSZ;
+    unsigned short* dst = Vs + (t % VST) * VSZ;
     const char* base = vb + (size_t)kv0 * 2;
     if (kv0 + KVT <= n) {
 #pragma unroll
@@ -215,15 +220,15 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
           dma16_v(src, lds_addr(dst + (vwave + 4 * j) * 512));
         }
     }
-    // the ones row of this stage: restrict it for a tail tile, restore it when the stage last held a tail tile (tile t-2)
+    // the ones row of this stage: restrict it for a tail tile, restore it when the stage last held a tail tile (tile t-VST)
     const bool tail = (kv0 + KVT > n);
     bool prev_tail = false;
-    if (t >= 2) {
-      const int t2 = t - 2;
+    if (t >= VST) {
+      const int t2 = t - VST;
       const int s2 = (t2 < T0) ? 0 : 1;
       prev_tail = ((s2 ? (t2 - T0) : t2) + 1) * KVT > p.n[s2];
     }
-    if (tail || prev_tail) issue_ones(t & 1, tail ? n - kv0 : KVT);
+    if (tail || prev_tail) issue_ones(t % VST, tail ? n - kv0 : KVT);
   };
 
   f32x16 o[2][NMT];
@@ -339,19 +344,34 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
       rebase_scores(1, t == 0);
     }
     unsigned acc = exp_pack(0);
-    pv(0, t & 1);
+    pv(0, t % VST);
     acc |= exp_pack(1);
     load_kf(kf, (t + 1) % 3);                        // next tile's K fragments (a stale stage after the last tile: unused)
-    pv(1, t & 1);
+    pv(1, t % VST);
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(kf[st][ks]));       // landed here, under the MFMAs
     return acc;
   };
-  auto end_tile = [&]() {
-    // this wave's DMA (issued at the top of the tile) has landed; the barrier publishes everyone's and retires the tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // End of a tile: the loads the NEXT tile needs have landed (this wave's share; the barrier publishes everyone's) and the
+  // tile is retired.  VA == 1: everything this wave issued is needed next -> vmcnt(0).  VA == 2 and `counted`: the loads
+  // issued at the top of THIS tile (this wave's n_mine K and V^T instructions for tile t+2: 3 on waves 0 / 1, 2 on waves
+  // 2 / 3 at d = 40) may stay in flight; everything older -- tile t+1's -- must be there.
+  int n_mine = 0;                                    // LDS-DMA instructions this wave issues per full tile (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < K_PER_WAVE; ++j) n_mine += (wave + 4 * j < K_INST) ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < V_PER_WAVE; ++j) n_mine += (vwave + 4 * j < V_INST) ? 1 : 0;
+  auto end_tile = [&](const bool counted) {
+    if (VA == 2 && counted) {
+      if (n_mine == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (n_mine == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (n_mine == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   };
   constexpr unsigned EXP_MASK = DT == IDF_BF16 ? 0x7f80u : 0x7c00u;     // all-ones exponent of a 16-bit half: inf / nan
@@ -374,6 +394,9 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
             mx = fmaxf(mx, fmaxf(Elem<DT>::to_f32((unsigned short)(v & 0xffffu)), Elem<DT>::to_f32((unsigned short)(v >> 16))));
           }
         mx = half_max(mx);
+        // growth beyond 2^40 in one tile is left to the exact pass as well: the rescale factor 2^-(log2 mx + SHIFT) must stay
+        // a normal fp32 number (v_exp_f32 flushes denormal results to 0, which would wipe O AND its denominator row)
+        bad |= !(mx <= 0x1p40f);
         raise_m(g, __builtin_amdgcn_logf(mx) + RefShift<DT>::v, false);           // v_log_f32 = log2; log2(0) = -inf: no raise
       }
       if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo_flag = 1;
@@ -392,30 +415,35 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[g][mt][r] = 0.0f;
     }
+    if (exact_all) {                                // the abandoned pass may have left a tail-restricted ones row behind
+      const unsigned short one = Elem<DT>::from_f32(1.0f);
+      for (int i = tid; i < VST * KVT; i += 256) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
+    }
     __syncthreads();                                // zero fill, ones row, ones fragment (or the abandoned pass) complete
     issue_k(0);
     issue_v(0);
     if (T > 1) issue_k(1);
+    if (VA == 2 && T > 1) issue_v(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     load_kf(kf, 0);
 
     // ---- tile 0: exact (fixes the reference value m of every query)
     if (T > 2) issue_k(2);
-    if (T > 1) issue_v(1);
+    if (T > VA) issue_v(VA);
     tile(TrueT{}, 0);
-    end_tile();
+    end_tile(false);
 
     int t = 1;
     if (!exact_all) {
-      // ---- steady state: the loads issued here (K(t+2), V^T(t+1)) are full tiles of segment 0: running scalar bases
+      // ---- steady state: the loads issued here (K(t+2), V^T(t+VA)) are full tiles of segment 0: running scalar bases
       const char* kptr = kbase0 + (size_t)3 * KVT * p.ldk[0] * 2;
-      const char* vptr = vbase0 + (size_t)2 * KVT * 2;
+      const char* vptr = vbase0 + (size_t)(1 + VA) * KVT * 2;
       const size_t kstep = (size_t)KVT * p.ldk[0] * 2;
       for (; t + 2 < F0; ++t) {
         // Every wave passed the barrier that ended tile t-1: K(t+1) and V^T(t) are visible, K(t-1) / V^T(t-1) are dead.
         unsigned short* kdst = Ks + ((t + 2) % 3) * KSZ;
-        unsigned short* vdst = Vs + ((t + 1) & 1) * VSZ;
+        unsigned short* vdst = Vs + ((t + VA) % VST) * VSZ;
 #pragma unroll
         for (int j = 0; j < K_PER_WAVE; ++j)
           if (wave + 4 * j < K_INST)
@@ -427,20 +455,20 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
         kptr += kstep;
         vptr += KVT * 2;
         const unsigned acc = tile(FalseT{}, t);
-        end_tile();
+        end_tile(true);
         after_tile(acc);
       }
     }
     // ---- remaining tiles (segment change, tail tiles, end of the key range; every tile of the fallback pass)
     for (; t < T; ++t) {
       if (t + 2 < T) issue_k(t + 2);
-      if (t + 1 < T) issue_v(t + 1);
+      if (t + VA < T) issue_v(t + VA);
       if (exact_all) {
         tile(TrueT{}, t);
-        end_tile();
+        end_tile(false);
       } else {
         const unsigned acc = tile(FalseT{}, t);
-        end_tile();
+        end_tile(false);
         after_tile(acc);
       }
     }
@@ -481,7 +509,9 @@ int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
   dim3 grid(nqb * p.H * B), block(256);
 #define IDF_ATTN4_CASE(KS, MT) \
   if (p.d == 8 * (2 * KS - 1)) { \
-    hipLaunchKernelGGL((attn4_kernel<DT, KS, MT>), grid, block, 0, s, p, nqb, idf_attn2_mode() == 6 ? 0 : 1); \
+    const int mode = idf_attn2_mode(); \
+    if (mode >= 7) hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 2>), grid, block, 0, s, p, nqb, mode == 8 ? 0 : 1); \
+    else hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1>), grid, block, 0, s, p, nqb, mode == 6 ? 0 : 1); \
     return idf_launch_status(); }
   IDF_ATTN4_CASE(2, 1)    // d = 24
   IDF_ATTN4_CASE(3, 2)    // d = 40

@@ -31,3 +31,6 @@ int idf_launch_attn2(const idfattn::AttnParams& p, int B, int dtype, hipStream_t
 // variant 4 (attention4.hip): max-free softmax with the reference value folded into the K.Q^T MFMA, K fragments read one
 // tile ahead, XCD-aware 1-D grid.  Selected by attention mode 5; same IDF_ATTN2_UNSUPPORTED contract.
 int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
+// variant 5 (attention5.hip): variant 4 as ONE 8-wave workgroup per 512 queries whose two waves per SIMD alternate between a
+// matrix phase and a scalar phase (modes 9 / 10 / 11).
+int idf_launch_attn5(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);

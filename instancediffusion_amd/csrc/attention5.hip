@@ -17,9 +17,12 @@
 // Differences forced by the phase split:
 //   * the guard fires in S(t), BEFORE P(t) enters O: a finite hit only schedules an exact max pass for tile t+1 (classic
 //     online-softmax step: O then holds tiles <= t); inf / nan or P >= 2^60 flags the workgroup to redo the block exactly;
-//   * K and V^T rings are 4 stages deep; waves 0-3 issue K(t+3) at the start of their M(t), waves 4-7 V^T(t+2) at the start
-//     of theirs; a wave ends an M phase with a counted s_waitcnt that leaves only that phase's loads in flight, so every
-//     load has a full tile period to land and is visible at least one phase before its first reader;
+//   * K and V^T rings are 4 stages deep; at the END of its S(t) -- behind its VALU stream, while the partner runs nothing
+//     but MFMAs -- a wave waits for the loads it issued one tile ago (s_waitcnt vmcnt(0): they have had a whole tile
+//     period) and issues the next batch: waves 0-3 K(t+3), waves 4-7 V^T(t+2); the barrier that follows publishes the
+//     landed batch at least one phase before its first reader.  ALL LDS fragment reads of an M phase (V^T(t-1), K(t))
+//     are issued in the S phase before it: the M phase is 28 MFMAs out of registers.  A wave runs its M phases at
+//     s_setprio 1 (see the main loop for why);
 //   * 512 queries per workgroup: K / V^T tiles are staged once for 8 waves (half the L2 -> LDS traffic of variant 4).
 #include "attn_core.h"
 
@@ -40,7 +43,18 @@ constexpr int RING = 4;                               // K and V^T ring stages
 __device__ __forceinline__ unsigned lds_addr5(const void* p) { return (unsigned)(size_t)p; }
 __device__ __forceinline__ void dma16_sv5(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds) {
   lds = __builtin_amdgcn_readfirstlane(lds);
+#ifdef IDF_ATTN5_BUFFER_DMA
+  // A/B: the same transfer as buffer_load ... lds through a 128-bit resource descriptor (base, no stride, no bound)
+  const unsigned long long a = (unsigned long long)sbase;
+  u32x4 srd;
+  srd[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  srd[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  srd[2] = 0xffffffffu;
+  srd[3] = 0x00020000u;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(srd) : "memory");
+#else
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");
+#endif
 }
 __device__ __forceinline__ void dma16_v5(const void* addr /* per lane */, unsigned lds) {
   lds = __builtin_amdgcn_readfirstlane(lds);
@@ -53,8 +67,24 @@ __device__ __forceinline__ void phase_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Optional per-segment cycle trace (tools/ubench/attn5_trace.hip builds this file with -DIDF_ATTN5_TRACE): s_memtime deltas
+// summed per segment over all tiles, written by waves 0 and 4 of block 0.  Costs ~10 % (s_memtime drains lgkmcnt).
+#ifdef IDF_ATTN5_TRACE
+__device__ unsigned long long idf_attn5_trace_buf[2][16];
+#define TR_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define TR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
+#define TR_DUMP if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) { for (int i = 0; i < 12; ++i) idf_attn5_trace_buf[wave >> 2][i] = tr_acc[i]; }
+#else
+#define TR_DECL
+#define TR(i)
+#define TR_DUMP
+#endif
+
 template <int DT> struct RefShift5;          // after an exact pass the largest P of a query is 2^-SHIFT (guard trigger: P >= 2)
-template <> struct RefShift5<IDF_BF16> { static constexpr float v = 7.0f; };
+// bf16 (8 exponent bits): the first tile's max maps to 2^-40 -- 167 binades of headroom above, 86 below before P flushes
+// to zero -- and NO per-tile guard: an overflow (inf in P or O) is caught once, at the end of the block.  fp16 (5 exponent
+// bits): P must stay near the top of its range, so the per-tile OR-bit guard (P >= 2 -> exact pass on the next tile) stays.
+template <> struct RefShift5<IDF_BF16> { static constexpr float v = 40.0f; };
 template <> struct RefShift5<IDF_F16> { static constexpr float v = 1.0f; };
 
 template <int DT, int NKS, int NMT>
@@ -149,7 +179,8 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
   const char* const vbase1 = reinterpret_cast<const char*>(p.vt[1] + (size_t)b * p.sV[1] + (size_t)(h * D) * p.ldv[1]);
 
   // issue this wave's share of K tile t; returns true when the counted end-of-phase wait applies (a full tile)
-  auto issue_k = [&](int t) -> bool {
+  // jsel = 0: instruction wi (the S-phase share), 1: instruction wi + 4 (the M-phase share), -1: both (prologue)
+  auto issue_k = [&](int t, int jsel) -> bool {
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
@@ -160,12 +191,13 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
       const char* base = kb + (size_t)kv0 * ldk * 2;
 #pragma unroll
       for (int j = 0; j < PER_WAVE; ++j)
-        if (wi + 4 * j < K_INST) dma16_sv5(base, seg ? koff[1][j] : koff[0][j], lds_addr5(dst + (wi + 4 * j) * 512));
+        if (wi + 4 * j < K_INST && (jsel < 0 || jsel == j))
+          dma16_sv5(base, seg ? koff[1][j] : koff[0][j], lds_addr5(dst + (wi + 4 * j) * 512));
       return true;
     }
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j)               // tail tile: rows beyond n are clamped to the last valid key
-      if (wi + 4 * j < K_INST) {
+      if (wi + 4 * j < K_INST && (jsel < 0 || jsel == j)) {
         const int c = (wi + 4 * j) * 64 + lane;
         const int row = c / DCH, col = (c - row * DCH) * 8;
         const int kr = min(kv0 + row, n - 1);
@@ -183,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
       dma16_v5(src, lds_addr5(Vs + stage * VSZ + V_INST * 512));
     }
   };
-  auto issue_v = [&](int t) -> bool {
+  auto issue_v = [&](int t, int jsel) -> bool {
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
@@ -200,11 +232,12 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
     if (!tail) {
 #pragma unroll
       for (int j = 0; j < PER_WAVE; ++j)
-        if (wi + 4 * j < V_INST) dma16_sv5(base, seg ? voff[1][j] : voff[0][j], lds_addr5(dst + (wi + 4 * j) * 512));
+        if (wi + 4 * j < V_INST && (jsel < 0 || jsel == j))
+          dma16_sv5(base, seg ? voff[1][j] : voff[0][j], lds_addr5(dst + (wi + 4 * j) * 512));
     } else {                                         // tail tile: 8-key chunks beyond n (n % 8 == 0) come from the zero page
 #pragma unroll
       for (int j = 0; j < PER_WAVE; ++j)
-        if (wi + 4 * j < V_INST) {
+        if (wi + 4 * j < V_INST && (jsel < 0 || jsel == j)) {
           const int vrow = (wi + 4 * j) * 8 + (lane >> 3);
           const int vch = (lane & 7) ^ ((vrow >> 1) & 7);
           const bool valid = (kv0 + vch * 8) < n;
@@ -213,20 +246,9 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
           dma16_v5(src, lds_addr5(dst + (wi + 4 * j) * 512));
         }
     }
-    if (tail || prev_tail) issue_ones(t % RING, tail ? n - kv0 : KVT);
+    if ((tail || prev_tail) && jsel <= 0) issue_ones(t % RING, tail ? n - kv0 : KVT);
     return !tail && !prev_tail;
   };
-  int n_mine = 0;                                    // LDS-DMA instructions this wave issues per full tile (wave-uniform)
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) n_mine += (wi + 4 * j < K_INST) ? 1 : 0;
-  // End of an M phase: everything this wave issued BEFORE this phase has landed (the barrier that follows publishes it);
-  // `counted`: the n_mine loads issued at the start of this phase may stay in flight.
-  auto wait_loads = [&](const bool counted) {
-    if (counted && n_mine == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (counted && n_mine == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
   f32x16 o[2][NMT];
   float m_run[2];                                   // the reference value m of the lane's query, 16-bit representable
   const int v_sw = (l31 >> 1) & 7;                  // V^T fragment rows are mt*32 + l31
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
   f32x16 s[2][2];                                    // [query group][kv half]
   u32x4 pk[2][4];                                    // packed P: [group][16-key step]
   u32x4 kf[2][NKS];                                  // K fragments of the next K.Q^T, read in the S phase before it
-  u32x4 vpre[NMT];                                   // first V^T fragments of the next P.V, read in the S phase before it
+  u32x4 vf[4][NMT];                                  // V^T fragments of the next P.V, read in the S phase before it
   auto load_kf = [&](int stage) {
     const unsigned short* Kc = Ks + stage * KSZ;
 #pragma unroll
@@ -252,10 +274,13 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
       kf[st][NKS - 1] = *reinterpret_cast<const u32x4*>(last);
     }
   };
-  auto load_vpre = [&](int stage) {
+  auto load_vf = [&](int stage) {
     const unsigned short* Vc = Vs + stage * VSZ + vfoff;
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) vpre[mt] = *reinterpret_cast<const u32x4*>(Vc + mt * 32 * KVT + ((hi ^ v_sw) * 8));
+    for (int step = 0; step < 4; ++step)
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+        vf[step][mt] = *reinterpret_cast<const u32x4*>(Vc + mt * 32 * KVT + (((step * 2 + hi) ^ v_sw) * 8));
   };
   auto qk = [&]() {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -266,26 +291,16 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
 #pragma unroll
         for (int g = 0; g < 2; ++g) s[g][st] = Elem<DT>::mfma32(kf[st][ks], qf[g][ks], ks == 0 ? zero : s[g][st]);
   };
-  // O^T += V^T P^T for both query groups: every V^T fragment feeds two MFMAs; fragments stream one 16-key step ahead
-  auto pv = [&](const int stage) {
-    const unsigned short* Vc = Vs + stage * VSZ + vfoff;
-    u32x4 a[2][NMT];
+  // O^T += V^T P^T for both query groups (every V^T fragment feeds two MFMAs), straight from registers: hipcc sinks LDS
+  // reads placed in the M phase next to their MFMAs (one exposed LDS latency per fragment), so they all live in the S phase.
+  auto pv = [&]() {
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) a[0][mt] = vpre[mt];
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-      if (step + 1 < 4) {
-        const int chunk = (step + 1) * 2 + hi;               // 8-key chunk of the tile
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          a[(step + 1) & 1][mt] = *reinterpret_cast<const u32x4*>(Vc + mt * 32 * KVT + ((chunk ^ v_sw) * 8));
-      }
+    for (int step = 0; step < 4; ++step)
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt) {
-        o[0][mt] = Elem<DT>::mfma32(a[step & 1][mt], pk[0][step], o[0][mt]);
-        o[1][mt] = Elem<DT>::mfma32(a[step & 1][mt], pk[1][step], o[1][mt]);
+        o[0][mt] = Elem<DT>::mfma32(vf[step][mt], pk[0][step], o[0][mt]);
+        o[1][mt] = Elem<DT>::mfma32(vf[step][mt], pk[1][step], o[1][mt]);
       }
-    }
   };
   auto half_max = [&](float mx) -> float {           // max over the two lane halves that share a query
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
@@ -341,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
   };
   constexpr unsigned EXP_MASK = DT == IDF_BF16 ? 0x7f80u : 0x7c00u;     // all-ones exponent of a 16-bit half: inf / nan
 
+  constexpr bool GUARD = DT == IDF_F16;            // per-tile overflow guard (see RefShift5)
   // S phase of tile t.  `exact`: max pass before the exponentials (tile 0, the tile after a guard hit, the fallback pass).
   // Returns whether the NEXT tile must be exact (guard hit: some P of this wave reached 2).
   auto s_phase = [&](const int t, const bool exact) -> bool {
@@ -350,13 +366,18 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
       rebase_scores(1, t == 0);
     }
     const unsigned acc = exp_pack();
-    load_kf((t + 1) % RING);                         // K(t+1) has been visible for a phase (a stale stage after the last tile)
-    load_vpre(t % RING);                             // V^T(t), for the P.V of this tile in the next M phase
+    // pin: P is packed HERE (LLVM otherwise sinks the exponentials towards their consumer, the P.V MFMAs behind the next
+    // barrier -- i.e. behind the loads below -- and the phase order this kernel is built on is gone)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) asm volatile("" ::"v"(pk[g][0]), "v"(pk[g][1]), "v"(pk[g][2]), "v"(pk[g][3]));
+    __builtin_amdgcn_sched_barrier(0);               // the reads below stay behind the exponentials (the scores are dead by then)
+    load_vf(t % RING);                               // V^T(t), for the P.V of this tile in the next M phase
+    load_kf((t + 1) % RING);                         // K(t+1), for the K.Q^T of that M phase (a stale stage after the last tile)
     bool hit = false;
-    if (__builtin_amdgcn_ballot_w64((acc & 0x40004000u) != 0u) != 0) {
-      // rare: bit 14 of a half (bf16 exponent >= 128 / fp16 exponent field >= 16), i.e. some P >= 2.  Finite and moderate:
-      // P(t) is valid, it enters O as it is; the next tile takes the exact pass (which raises m if the level stays high).
-      // Inf / nan / beyond 2^60 (O could overflow): flag the workgroup to redo the block with the exact max on every tile.
+    if (GUARD && __builtin_amdgcn_ballot_w64((acc & 0x40004000u) != 0u) != 0) {
+      // rare: bit 14 of a half (fp16 exponent field >= 16), i.e. some P >= 2.  Finite: P(t) is valid and enters O as it is;
+      // the next tile takes the exact pass (which raises m if the level stays high).  Inf / nan: flag the workgroup to
+      // redo the block with the exact max on every tile.
       hit = true;
       bool bad = false;
 #pragma unroll
@@ -367,7 +388,6 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
           for (int w = 0; w < 4; ++w) {
             const unsigned v = pk[g][step][w];
             bad |= ((v & EXP_MASK) == EXP_MASK) | (((v >> 16) & EXP_MASK) == EXP_MASK);
-            bad |= !(fmaxf(Elem<DT>::to_f32((unsigned short)(v & 0xffffu)), Elem<DT>::to_f32((unsigned short)(v >> 16))) <= 0x1p60f);
           }
       if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo_flag = 1;
     }
@@ -392,37 +412,78 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(const AttnParams p, const
     __syncthreads();                                // zero fill, ones rows, ones fragment (or the abandoned pass) complete
     // prologue loads: K(0..2) by group 0, V^T(0..1) by group 1
     if (grp == 0) {
-      issue_k(0);
-      if (T > 1) issue_k(1);
-      if (T > 2) issue_k(2);
+      issue_k(0, -1);
+      if (T > 1) issue_k(1, -1);
+      if (T > 2) issue_k(2, -1);
     } else {
-      issue_v(0);
-      if (T > 1) issue_v(1);
+      issue_v(0, -1);
+      if (T > 1) issue_v(1, -1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     load_kf(0);
 
+    // Priorities (prio == 1): a wave holds s_setprio 1 through its M phases and 0 through its S phases (switched just
+    // before the barrier that ends a phase).  Without it the YOUNGER wave of a SIMD (waves 4-7) loses every VALU / SMEM /
+    // VMEM arbitration against its older partner: ~450 cycles stalled at the start of each of its M phases and its LDS-DMA
+    // instructions wait for a gap in the partner's exponentials (profiles/r02_attn5_trace*.log).
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);    // prio == 2 (A/B): the other way round, S phases at priority 1
     if (grp == 1) phase_barrier();                   // waves 4-7 run one phase behind waves 0-3
     bool exact_next = true;                          // tile 0 fixes the reference value of every query
+    TR_DECL
     for (int t = 0; t < T; ++t) {
-      // ---- M phase: loads for later tiles, P.V of tile t-1, K.Q^T of tile t
-      if (prio) __builtin_amdgcn_s_setprio(1);
-      bool counted = false;                          // nothing issued in this phase: everything older must land
-      if (grp == 0) { if (t + 3 < T) counted = issue_k(t + 3); }
-      else { if (t + 2 < T) counted = issue_v(t + 2); }
-      if (t > 0) pv((t - 1) % RING);
+      // ---- M phase: P.V of tile t-1, K.Q^T of tile t -- 28 MFMAs out of registers.  No VALU, no LDS reads.  Behind the
+      // MFMAs: the PARTNER group's fifth LDS-DMA instruction of this step (see below).
+      TR(0)
+      if (t > 0) pv();
+      TR(2)
       qk();
-      wait_loads(counted);
-      if (prio) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) asm volatile("" ::"v"(s[g][0]), "v"(s[g][1]));      // pin: the MFMAs are issued in this phase
+      if (K_INST > 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (grp == 1) { if (t + 3 < T) issue_k(t + 3, 1); }          // step 2t+1: group 0 is in S(t) issuing K(t+3)[0..3]
+        else if (t > 0) { if (t + 1 < T) issue_v(t + 1, 1); }        // step 2t: group 1 is in S(t-1) issuing V^T(t+1)[0..3]
+      }
+      if (prio == 1) __builtin_amdgcn_s_setprio(0);
+      if (prio == 2) __builtin_amdgcn_s_setprio(1);
+      TR(3)
       phase_barrier();
-      // ---- S phase
+      TR(5)
+      // ---- S phase: exponentials, packing, the LDS reads of the next M phase (+ guard); then, behind the VALU stream and
+      // while the partner wave runs nothing but MFMAs, ONE LDS-DMA instruction per wave: an instruction costs its wave
+      // 200 - 280 cycles of issue (profiles/r02_attn5_trace8.log), so a tile's five K (V^T) instructions go out as four from
+      // the four waves of the group in its S phase plus one from a wave of the other group behind its MFMAs in the same
+      // step.  Before issuing, a wave waits for what it issued earlier (s_waitcnt vmcnt(0): at least a phase old); the
+      // barrier that follows publishes it, at least one phase before its first reader.
       exact_next = s_phase(t, exact_next || exact_all);
+      TR(6)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TR(4)
+      if (grp == 0) { if (t + 3 < T) issue_k(t + 3, 0); }
+      else { if (t + 2 < T) issue_v(t + 2, 0); }
+      if (prio == 1) __builtin_amdgcn_s_setprio(1);
+      if (prio == 2) __builtin_amdgcn_s_setprio(0);
+      TR(1)
       phase_barrier();
+      TR(7)
     }
-    pv((T - 1) % RING);                              // the last tile's P.V (the other group is in its last S phase / done)
+    TR_DUMP
+    pv();                                            // the last tile's P.V (the other group is in its last S phase / done)
     if (grp == 0) phase_barrier();
     if (exact_all) break;
+    {
+      // the common path never looked at P (bf16) / only looked for P >= 2 (fp16): an overflow anywhere shows here, as a
+      // non-finite accumulator or denominator
+      bool bad = false;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bad |= !(__builtin_fabsf(o[g][mt][r]) < INFINITY);
+      if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo_flag = 1;
+    }
     __syncthreads();                                // every wave's redo_flag store is visible
     if (redo_flag == 0) break;
     exact_all = true;                               // workgroup-uniform: all eight waves redo the block
@@ -458,10 +519,13 @@ template <int DT>
 int launch_attn5(const AttnParams& p, int B, hipStream_t s) {
   const int nqb = (p.nq + 511) / 512;
   dim3 grid(nqb * p.H * B), block(512);
-  const int mode = idf_attn2_mode();                 // 9: default, 10: plain block order, 11: s_setprio 1 in the M phases
+  // modes 9 .. 14: (mode - 9) & 1 = plain block order instead of the XCD-aware one; (mode - 9) >> 1 = priorities: 0 none,
+  // 1 s_setprio 1 through the M phases, 2 through the S phases
+  const int mode = idf_attn2_mode() - 9;
+  const int xcd = (mode & 1) ? 0 : 1, prio = (mode >> 1) & 3;
 #define IDF_ATTN5_CASE(KS, MT) \
   if (p.d == 8 * (2 * KS - 1)) { \
-    hipLaunchKernelGGL((attn5_kernel<DT, KS, MT>), grid, block, 0, s, p, nqb, mode == 10 ? 0 : 1, mode == 11 ? 1 : 0); \
+    hipLaunchKernelGGL((attn5_kernel<DT, KS, MT>), grid, block, 0, s, p, nqb, xcd, prio); \
     return idf_launch_status(); }
   IDF_ATTN5_CASE(2, 1)    // d = 24
   IDF_ATTN5_CASE(3, 2)    // d = 40

@@ -22,7 +22,7 @@ struct AttnParams {
 // 64-queries-per-wave LDS-DMA kernel (attention2.hip); IDF_ATTN2_UNSUPPORTED when the shape does not qualify.
 #define IDF_ATTN2_UNSUPPORTED (-100)
 #ifndef IDF_ATTN2_DEFAULT
-#define IDF_ATTN2_DEFAULT 3
+#define IDF_ATTN2_DEFAULT 5
 #endif
 extern long long idf_stat_attn2_launches;
 int idf_attn2_mode();

@@ -600,7 +600,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
     return idf_big_set_geom(value);
   }
   if (knob == IDF_TUNE_ATTN2) {
-    if (value < 0 || value > 11) return IDF_E_ARG;
+    if (value < 0 || value > 14) return IDF_E_ARG;
     return idf_attn2_set_mode(value);
   }
   return IDF_E_ARG;

@@ -475,9 +475,9 @@ def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
 # ---------------------------------------------------------------------------------------------------
 # attention variant 2 (attention2.hip: 64 queries per wave, LDS-DMA staging), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11],
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13],
                 ids=["v2", "v3-pipelined", "v2-lazy", "v3-pipelined-lazy", "v4", "v4-plain-grid", "v4-deep", "v4-deep-plain-grid",
-                     "v5-pingpong", "v5-plain-grid", "v5-setprio"])
+                     "v5-pingpong", "v5-plain-grid", "v5-plain-prioM", "v5-prioS"])
 def attn2(request):
     from instancediffusion_amd import _lib
     lib = _lib.load()
@@ -606,7 +606,13 @@ def test_attention_v4_reference_value_paths(ref, attn4, case):
     tol = BF16_TOL if dt == torch.bfloat16 else 2.0 ** -10
     err, mx = rel_rms(out, want), relmax(out, want)
     print(f"[parity] attention v4 {case} {dt}: rel-rms {err:.3e} max-rel {mx:.3e}")
-    assert mx < 2 * tol and err < tol
+    # "overflow": scores of +-100 .. 360 log2 units.  Q enters the MFMA pre-multiplied by scale*log2(e) and rounded to the
+    # 16-bit type once (as in variant 2's lazy mode and in torch's math SDPA), i.e. a score carries a relative error of up to
+    # 2^-9 (bf16) / 2^-12 (fp16): +-0.5 / +-0.06 log2 units at |score| = 300.  For the handful of queries whose spike key
+    # competes with another key within that margin the softmax weights shift by a few percent -- the worst element is
+    # allowed 4x the usual bound there, the rel-RMS bound (which is what the UNet sees) stays.
+    mx_tol = 8 * tol if case == "overflow" else 2 * tol
+    assert mx < mx_tol and err < tol
 
 
 # ---------------------------------------------------------------------------------------------------

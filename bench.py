@@ -8,8 +8,12 @@
 Workload (BASELINE.json metric): SD-1.5 InstanceDiffusion UNet (1.228 B parameters, seeded
 synthetic weights -- no checkpoints exist offline), 512x512 images = 64x64 latents, 50 PLMS steps, classifier-free
 guidance 7.5, N=8 box instances, Multi-instance Sampler mis=0.36 (=> 406 UNet forwards per image), alpha schedule
-[0.8, 0, 0.2].  One "step" = one full sampling of the global image batch (images_per_gpu x n_gpus images);
-weak scaling.  Inputs are resident in HBM before the timed region.  VAE decode is outside the path.
+[0.8, 0, 0.2].  One "step" = one full sampling of the global image batch.  Default: weak scaling, images_per_gpu x n_gpus
+images per step; ``--images-total K`` fixes the global batch instead (strong scaling, e.g. 8 images on 1 / 2 / 4 / 8 GPUs).
+At n_gpus > 1 the (instance, image) work units of MIS phase 1 are sharded over the ranks by ``--sharding``: "instance"
+(default; owner = (image + instance) mod N: the N+1 trajectories of every image are spread over the GPUs and the merge is
+a real RCCL all-reduce of partial latent sums -- north_star's split) or "image" (owner = image mod N: replicas, the
+all-reduce adds zeros).  Inputs are resident in HBM before the timed region.  VAE decode is outside the path.
 
 Prints ONE JSON line on rank 0 with the driver contract fields plus
   "roofline"     -- dominant kernel's achieved TFLOP/s (algorithmic flops / HIP-event duration) vs 2.5 PF bf16 MFMA
@@ -160,7 +164,7 @@ def pmc_traffic(op_name, batch):
         return None
 
 
-def measure_roofline(engine, batch):
+def measure_roofline(engine, batch, fuser_on=True):
     """One instrumented eager forward at the phase-1 batch: per-kernel-family durations from HIP events."""
     dev = engine.device
     cond = engine._slots[batch]
@@ -172,7 +176,7 @@ def measure_roofline(engine, batch):
         timer = OpTimer(real)
         engine.ops = timer
         try:
-            engine._forward_ops(x, t, cond, eps, True)
+            engine._forward_ops(x, t, cond, eps, fuser_on)
         finally:
             engine.ops = real
     agg = timer.summary()
@@ -189,7 +193,8 @@ def measure_roofline(engine, batch):
     pmc = pmc_traffic(name, batch)
     # `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
     # WRITE_SIZE, separate runs), averaged over the family's launches of one forward at this batch; null without a pass
-    return dict(bound="mfma", kernel=kern, achieved=round(achieved, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
+    return dict(_flops_per_row=sum(v["flops"] for v in agg.values()) / batch,
+                bound="mfma", kernel=kern, achieved=round(achieved, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
                 frac=round(achieved / PEAK_MFMA_TF, 4),
                 traffic=None if pmc is None else float(pmc["hbm_bytes_per_launch"]), traffic_unit="bytes/launch",
                 traffic_source=None if pmc is None else pmc.get("source"),
@@ -222,9 +227,22 @@ def cpu_baseline(cfg, sd, host_inputs, budget_s=25.0):
             times.append(time.time() - t0)
     t_fwd = sorted(times)[len(times) // 2]
     nf = n_forwards(N_INST, S_STEPS, MIS)
+    # the extrapolation factor, checked: the port's own Multi-instance Sampler (S = 50, N = 8, mis 0.36, CFG) driven with
+    # a forward that only counts its calls (each call = one B = 1 UNet forward of the reference's serial loop)
+    class _Counting(ref_cpu.OracleModel):
+        def __call__(self, inp):
+            self.n_forward += 1
+            return torch.zeros_like(inp["x"])
+    cm = _Counting(sd, cfg, None)
+    x1 = x.clone()
+    ins = [dict(x=x1, timesteps=None, context=ctx, grounding_input=g) for _ in range(N_INST + 1)]
+    with torch.no_grad():
+        ref_cpu.plms_sample_mis(cm, S_STEPS, ins, ctx, GUIDANCE, MIS, alpha_type=None)
+    assert cm.n_forward == nf, (cm.n_forward, nf)
     return dict(value=1.0 / (nf * t_fwd), unit="img/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{len(times)} timed full-size UNet forwards (B=1, 64x64 latent, fp32, median {t_fwd:.3f} s) "
-                       f"x {nf} forwards/image (extrapolated)")
+                       f"x {nf} forwards/image (extrapolated; {nf} = UNet calls counted in a full S=50 N=8 mis=0.36 run of the "
+                       f"port's sampler with a call-counting forward)")
 
 
 def main():
@@ -234,6 +252,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images-per-gpu", type=int, default=32)  # 32 images x (8+1) trajectories x cond/uncond = 9 forwards of 64 rows per MIS step
     ap.add_argument("--max-units", type=int, default=32, help="MIS phase-1 (instance, image) units per batched forward")
+    ap.add_argument("--images-total", type=int, default=0,
+                    help="strong scaling: fix the GLOBAL images per step (split over the ranks) instead of images per GPU")
+    ap.add_argument("--sharding", choices=["auto", "image", "instance"], default="instance",
+                    help="MIS phase-1 unit ownership at n_gpus > 1 (host/samplers.py); no effect at 1 GPU")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="storage / MFMA input type of the headline run")
+    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the short leg in the other 16-bit type")
+    ap.add_argument("--no-strong-leg", action="store_true", help="at n_gpus > 1: skip the short strong-scaling leg (8 images total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -263,20 +288,12 @@ def main():
     from instancediffusion_amd.host.samplers import PLMSSamplerInst
     cfg = dict(SD15_BOX_CFG)
     model, sd = build_model(cfg)
-    n_images = args.images_per_gpu * world
-    inputs, uc, gi, host_inputs = make_inputs(cfg, n_images, dev)
-    model.grounding_tokenizer_input = gi
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
-    _ = model.engine                                              # pack weights into HBM (bf16 GEMM images)
-    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=ALPHA_TYPE),
-                              set_alpha_scale=set_alpha_scale, mis=MIS, max_units=args.max_units)
-    shape = (n_images, 4, LATENT, LATENT)
-
-    def one_step():
-        # NOTE (reference quirk kept): the first-conv swap at alpha == 0 is never undone (openaimodel.py:469-480),
-        # so every image batch after the first starts with the SD first conv -- same arithmetic cost either way.
-        ins = [dict(d) for d in inputs]
-        return sampler.sample(S=S_STEPS, shape=shape, input=ins, uc=uc, guidance_scale=GUIDANCE)
+    torch_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}
+    nf = n_forwards(N_INST, S_STEPS, MIS)
+    if args.images_total:
+        assert args.images_total >= 1
+    n_images = args.images_total if args.images_total else args.images_per_gpu * world
 
     def sync():
         torch.cuda.synchronize()
@@ -284,41 +301,108 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = one_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out).all()
+    def run_leg(dtype_name, n_img, steps, warmup, sharding):
+        """One measurement: `warmup` untimed + `steps` timed samplings of n_img images; returns (img/s, ms/step, rows)."""
+        model.compute_dtype = torch_dtype[dtype_name]
+        model.invalidate_engine()
+        eng = model.engine                                        # packs the weights into HBM in this storage type
+        inputs, uc, gi, host_inputs = make_inputs(cfg, n_img, dev)
+        model.grounding_tokenizer_input = gi
+        sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=ALPHA_TYPE),
+                                  set_alpha_scale=set_alpha_scale, mis=MIS, max_units=args.max_units, unit_sharding=sharding)
+        shape = (n_img, 4, LATENT, LATENT)
+        rows = {True: 0, False: 0}                                # forward rows executed on this rank, fuser on / off
+        real_forward = eng.forward_cond
 
+        def counting_forward(x, t, cond, out=None):
+            rows[eng.fuser_scale != 0.0] += int(x.shape[0])
+            return real_forward(x, t, cond, out=out)
+        eng.forward_cond = counting_forward
+
+        def one_step():
+            # NOTE (reference quirk kept): the first-conv swap at alpha == 0 is never undone (openaimodel.py:469-480),
+            # so every image batch after the first starts with the SD first conv -- same arithmetic cost either way.
+            ins = [dict(d) for d in inputs]
+            return sampler.sample(S=S_STEPS, shape=shape, input=ins, uc=uc, guidance_scale=GUIDANCE)
+
+        for _ in range(warmup):
+            out = one_step()
+        sync()
+        rows[True] = rows[False] = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = one_step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed, float(rows[True]), float(rows[False])], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+            elapsed, rows[True], rows[False] = float(tt[0]), int(tt[1]), int(tt[2])
+        assert torch.isfinite(out).all()
+        eng.forward_cond = real_forward
+        return dict(value=n_img * steps / elapsed, ms_per_step=elapsed / max(steps, 1) * 1e3, images=n_img, steps=steps,
+                    rows_on=rows[True], rows_off=rows[False], host_inputs=host_inputs)
+
+    main_leg = run_leg(args.dtype, n_images, args.steps, args.warmup, args.sharding)
+    value = main_leg["value"]
+    line = None
     if rank == 0:
-        ms_per_step = elapsed / max(args.steps, 1) * 1e3
-        value = n_images * args.steps / elapsed
-        nf = n_forwards(N_INST, S_STEPS, MIS)
         line = {
             "metric": "images/sec at 512x512, 50 PLMS steps, N=8 instances (Multi-instance Sampler)",
             "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "ms_per_step": round(main_leg["ms_per_step"], 2), "higher_is_better": True,
+            "scaling": "strong" if args.images_total else "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "C3: SD-1.5 InstanceDiffusion UNet (1.228B params, seeded random weights), 64x64 latent "
                                    "(512x512), 50 PLMS steps, CFG 7.5, N=8 boxes, MIS 0.36, alpha [0.8,0,0.2]",
-                       "images_per_gpu": args.images_per_gpu, "global_images_per_step": n_images,
-                       "unet_forwards_per_image": nf, "parallelism": f"mis-unit-shard x{world} + image-shard x{world}"},
+                       "images_per_gpu": None if args.images_total else args.images_per_gpu,
+                       "global_images_per_step": n_images, "unet_forwards_per_image": nf,
+                       "sharding": args.sharding if world > 1 else "none (1 GPU)",
+                       "parallelism": f"MIS (instance, image) units sharded x{world} [{args.sharding}], one RCCL all-reduce at "
+                                      f"the merge; phase 2 sharded over images x{world}"},
+            # reference-algorithmic work: every forward the reference runs (406 per image) at its own 1227.3 GFLOP
             "whole_step_algorithmic_tflops_per_gpu": round(value * nf * GFLOP_PER_FWD / 1e3 / world, 1),
             "whole_step_frac_of_mfma_peak": round(value * nf * GFLOP_PER_FWD / 1e3 / world / PEAK_MFMA_TF, 4),
         }
-        if not args.no_roofline:
-            phase1_batch = max(model.engine._slots.keys())
-            line["roofline"] = measure_roofline(model.engine, phase1_batch)
-        if not args.no_cpu_baseline and world == 1:              # reported at N=1 only (the host cores are shared at N>1)
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, host_inputs)
+    eng = model.engine
+    if rank == 0 and not args.no_roofline:
+        phase1_batch = max(eng._slots.keys())
+        line["roofline"] = measure_roofline(eng, phase1_batch, True)
+        # executed work (SURVEY §8d): what the engine really ran after the exact hoists -- forward ROWS counted in the timed
+        # region (first-evaluation de-duplication included) x the GEMM / conv / attention flops of one instrumented row,
+        # with the fuser on and off (alpha == 0 steps); UniFusion and the grounding-token K/V run once per conditioning,
+        # outside the forwards, and are not counted
+        off = measure_roofline(eng, phase1_batch, False)
+        f_on = line["roofline"].pop("_flops_per_row")
+        f_off = off["_flops_per_row"]
+        ex_tf = (main_leg["rows_on"] * f_on + main_leg["rows_off"] * f_off) / 1e12          # all ranks, timed region
+        secs = main_leg["ms_per_step"] * 1e-3 * args.steps
+        line["executed"] = dict(
+            tflop_per_image=round(ex_tf / (n_images * args.steps), 1), reference_tflop_per_image=round(nf * GFLOP_PER_FWD / 1e3, 1),
+            forward_rows_per_image=round((main_leg["rows_on"] + main_leg["rows_off"]) / (n_images * args.steps), 1),
+            gflop_per_row_fuser_on=round(f_on / 1e9, 1), gflop_per_row_fuser_off=round(f_off / 1e9, 1),
+            tflops_per_gpu=round(ex_tf / secs / world, 1), frac_of_mfma_peak=round(ex_tf / secs / world / PEAK_MFMA_TF, 4))
+    if rank == 0 and not args.no_cpu_baseline and world == 1:    # reported at N=1 only (the host cores are shared at N>1)
+        line["cpu_baseline"] = cpu_baseline(cfg, sd, main_leg["host_inputs"])
+    # ---- short extra legs (outside the headline's timed region; each its own warm-up + timed samplings)
+    if world > 1 and not args.no_strong_leg and not args.images_total:
+        # strong scaling at the reference's own batch: 8 images in total (inference.py num_images), split over the ranks
+        k = 8
+        leg = run_leg(args.dtype, k, 1, 1, args.sharding)
+        if rank == 0:
+            line["strong_scaling_leg"] = dict(global_images=k, value=round(leg["value"], 4), unit="img/s", steps=1, warmup=1,
+                                              ms_per_step=round(leg["ms_per_step"], 2), sharding=args.sharding,
+                                              forward_rows_per_image=round((leg["rows_on"] + leg["rows_off"]) / k, 1))
+    if not args.no_alt_dtype:
+        alt = "fp16" if args.dtype == "bf16" else "bf16"
+        leg = run_leg(alt, n_images, 1, 1, args.sharding)
+        if rank == 0:
+            line["alt_dtype_leg"] = dict(dtype=alt, value=round(leg["value"], 4), unit="img/s", steps=1, warmup=1,
+                                         ms_per_step=round(leg["ms_per_step"], 2),
+                                         note="same workload in the other 16-bit storage type (the reference's GPU path is fp16 "
+                                              "autocast, inference.py:94); fp16 parity is 10x tighter, MFMA rate identical")
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

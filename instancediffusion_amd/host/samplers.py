@@ -211,45 +211,51 @@ class PLMSSamplerInst(_PLMSBase):
             units = [(j, b) for j in range(n_all) for b in range(B) if (b + j) % world == rank]
         mine = [b for b in range(B) if b % world == rank]                     # images this rank owns in phase 2
 
-        # Conditioning (UniFusion tokens + per-layer K/V caches) only for the images THIS rank touches: with image
-        # sharding that is B / world images, so per-rank setup work and HBM stay constant as ranks are added (weak
-        # scaling); with one rank it is every image.  One bank of all conditionings; batches are assembled by a single
-        # row gather straight into the engine's static slot: row j*Bl + loc[b] = (instance j, image b),
-        # row n_all*Bl + loc[b] = unconditional of image b.
-        need = sorted({b for (_, b) in units} | set(mine))
-        loc = {b: k for k, b in enumerate(need)}
-        Bl = len(need)
-        sel = torch.tensor(need, device=dev, dtype=torch.long)
+        # Conditioning (UniFusion tokens + per-layer K/V caches) only for the (input, image) pairs THIS rank touches: input j
+        # is prepared on the images of this rank's units (j, b) -- with either ownership rule that is B / world images per
+        # input, so per-rank setup work and HBM stay constant as ranks are added (weak scaling); the unconditional branch
+        # is prepared on the union.  One bank of all conditionings; batches are assembled by a single row gather straight
+        # into the engine's static slot.
+        need_j = [sorted({b for (jj, b) in units if jj == j} | (set(mine) if j == 0 else set())) for j in range(n_all)]
+        need_u = sorted({b for (_, b) in units} | set(mine))
+        row_of: Dict[tuple, int] = {}
+        off = 0
+        for j in range(n_all):
+            for k, b in enumerate(need_j[j]):
+                row_of[(j, b)] = off + k
+            off += len(need_j[j])
+        row_unc = {b: off + k for k, b in enumerate(need_u)}
 
-        def take(v):
-            if not torch.is_tensor(v) or v.dim() == 0 or v.shape[0] != B or Bl == B:
+        def take(v, imgs):
+            if not torch.is_tensor(v) or v.dim() == 0 or v.shape[0] != B or len(imgs) == B:
                 return v
             if v.stride(0) == 0:                                               # batch-broadcast view stays a view
-                return v[:1].expand(Bl, *v.shape[1:])
-            return v.index_select(0, sel.to(v.device))
+                return v[:1].expand(len(imgs), *v.shape[1:])
+            return v.index_select(0, torch.tensor(imgs, device=v.device, dtype=torch.long))
 
-        def local(inp):
+        def local(inp, imgs):
             d = dict(inp)
-            d["context"] = take(inp["context"])
+            d["context"] = take(inp["context"], imgs)
             if "grounding_input" in inp:
                 gin = inp["grounding_input"]
-                d["grounding_input"] = {k: take(v) for k, v in gin.items()}
-                if torch.is_tensor(gin.get("att_masks")) and Bl != B:
+                d["grounding_input"] = {k: take(v, imgs) for k, v in gin.items()}
+                if torch.is_tensor(gin.get("att_masks")) and len(imgs) != B:
                     # attention.py:200 decides mask / no mask on the WHOLE per-call tensor: take that decision here, on
                     # the un-sharded batch, so that a rank's row subset cannot flip it (results independent of world)
                     d["grounding_input"]["att_masks_any"] = bool((gin["att_masks"] > 0).any())
             else:
-                d["grounding_input"] = self.model.grounding_tokenizer_input.get_null_input(batch=Bl)
+                d["grounding_input"] = self.model.grounding_tokenizer_input.get_null_input(batch=len(imgs))
             return d
 
-        conds = [self._cond(local(inp)) for inp in input_all] if Bl else []
-        cond_u = self._uncond(take(uc)) if (guided and Bl) else None
-        bank = type(conds[0]).cat(conds + ([cond_u] if guided else [])) if Bl else None
+        conds = [self._cond(local(input_all[j], need_j[j])) for j in range(n_all) if need_j[j]]
+        cond_u = self._uncond(take(uc, need_u)) if (guided and need_u) else None
+        parts = conds + ([cond_u] if cond_u is not None else [])
+        bank = type(parts[0]).cat(parts) if parts else None
 
         def rows(units):
-            r = [j * Bl + loc[b] for (j, b) in units]
+            r = [row_of[u] for u in units]
             if guided:
-                r += [n_all * Bl + loc[b] for (_, b) in units]
+                r += [row_unc[b] for (_, b) in units]
             return torch.tensor(r, device=dev, dtype=torch.long)
 
         # Reference quirk: restore_first_conv_from_SD is never undone, so if alpha hits 0 inside phase 1 the LATER
@@ -273,7 +279,7 @@ class PLMSSamplerInst(_PLMSBase):
         if guided and same_start and units and mis_step > 0 and not serial:
             self._apply_alpha(alphas, 0)
             imgs = sorted({b for (_, b) in units})
-            row_ids = [j * Bl + loc[b] for (j, b) in units] + [n_all * Bl + loc[b] for b in imgs]
+            row_ids = [row_of[u] for u in units] + [row_unc[b] for b in imgs]
             row_img = [b for (_, b) in units] + imgs
             first_idx = {u: k for k, u in enumerate(units)}
             first_unc = {b: len(units) + k for k, b in enumerate(imgs)}

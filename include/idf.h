@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IDF_ABI_VERSION 1
+#define IDF_ABI_VERSION 2
 
 enum { IDF_BF16 = 0, IDF_F16 = 1 };                 /* 16-bit storage / MFMA input type */
 enum { IDF_E_ARG = -1, IDF_E_ALIGN = -2, IDF_E_UNSUPPORTED = -3 };
@@ -36,7 +36,16 @@ enum {
   IDF_EPI_GELU     = 32,   /* out = gelu_erf(acc + bias)                                                   */
   IDF_EPI_GEGLU    = 64,   /* weight rows interleaved [32 value | 32 gate] per 64; out[m][j] = v * gelu(g) */
   IDF_EPI_OUT_F32  = 128,  /* store fp32 instead of 16-bit                                                 */
-  IDF_EPI_OUT_NCHW = 256   /* conv only: store fp32 NCHW [B, n_valid, Ho, Wo] (final out conv)             */
+  IDF_EPI_OUT_NCHW = 256,  /* conv only: store fp32 NCHW [B, n_valid, Ho, Wo] (final out conv)             */
+  /* LayerNorm of an operand folded into the GEMM (attention.py:294-295,320-322: x -> LN(x) -> Linear):
+   *   LN(x) W^T = rstd_m * (x (gamma*W)^T - mu_m * c) + d,   c[n] = sum_k (gamma*W)[n][k],  d[n] = sum_k beta[k] W[n][k] (+ bias[n])
+   * so the raw 16-bit x goes through the MFMAs against the gamma-folded weight and the epilogue applies the per-row
+   * statistics -- the normalised activation is never written to or read from HBM.  ln_stats = [rows][2] f32 (mu, rstd) of
+   * the NORMALISED operand: LN_ROW = A's rows (index m); LN_COL = W's rows (index n: the transposed-V projection, whose
+   * "weight" operand is the token matrix).  ln_c is indexed the other way (n for LN_ROW, m for LN_COL); d travels as
+   * `bias` (LN_ROW, needs BIAS) / `rowvec` (LN_COL).  With GEGLU both accumulators of a pair are corrected before the GELU. */
+  IDF_EPI_LN_ROW   = 512,
+  IDF_EPI_LN_COL   = 1024
 };
 
 int idf_abi_version(void);
@@ -77,8 +86,19 @@ typedef struct {
   int epi; int dtype;
   void* ws; long long ws_bytes;       /* optional fp32 split-K workspace (NULL = never split); used when the tile   */
                                       /* grid cannot fill 256 CUs: slices write partial slabs, a reducer applies epi */
+  /* LayerNorm folded into the GEMM (IDF_EPI_LN_ROW / IDF_EPI_LN_COL, see above) */
+  const float* ln_stats; long long stride_ln_stats;   /* [rows][2] (mu, rstd) of the normalised operand; batch stride in floats */
+  const float* ln_c;                  /* f32 [N] (LN_ROW) / [M] (LN_COL)                                      */
+  const float* ln_d;                  /* LN_COL only: f32 [M] added per output row                             */
+  /* optional by-product: (mu, rstd) of every OUTPUT row (over its N columns, of the 16-bit-rounded values), for a
+   * LayerNorm that follows -- out_stats = f32 [batch*M][2], eps = out_stats_eps.  NULL = none.  Not with GEGLU / OUT_F32. */
+  float* out_stats; float out_stats_eps;
 } idf_gemm_args;
 int idf_gemm(const idf_gemm_args* a, void* stream);
+
+/* (mu, rstd) of every row of a 16-bit [M, C] matrix (exact two-pass, fp32): stats[m] = (mean, 1/sqrt(var + eps)).
+ * The stand-alone producer of `ln_stats` (idf_gemm's out_stats is the fused one).  C % 8 == 0, C <= 1536.          */
+int idf_row_stats(const void* x, int ldx, float* stats, int M, int C, float eps, int dtype, void* stream);
 
 /* ---- 3x3 convolution, pad 1, NHWC, implicit GEMM ---------------------------------------------------------
  * Replaces nn.Conv2d(k=3) call sites openaimodel.py:185,211 (ResBlock), :132-134 (Downsample, stride 2),

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDF_LIB_PATH", os.path.join(_HERE, "libidf_gfx950.so"))   # override: A/B builds only
 
 IDF_BF16, IDF_F16 = 0, 1
+EPI_LN_ROW, EPI_LN_COL = 512, 1024
 EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \
     1, 2, 4, 8, 16, 32, 64, 128, 256
 
@@ -24,7 +25,9 @@ class GemmArgs(C.Structure):
                 ("lda", ci), ("ldw", ci), ("ldo", ci), ("ldr", ci), ("ld_rowbias", ci),
                 ("rows_per_batch", ci),
                 ("batch", ci), ("strideA", ll), ("strideW", ll), ("strideO", ll), ("strideR", ll),
-                ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll)]
+                ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll),
+                ("ln_stats", vp), ("stride_ln_stats", ll), ("ln_c", vp), ("ln_d", vp),
+                ("out_stats", vp), ("out_stats_eps", cf)]
 
 
 class ConvArgs(C.Structure):
@@ -57,6 +60,7 @@ SYMBOLS = {
     "idf_groupnorm_ws_floats": (ll, [ci, ci]),
     "idf_groupnorm": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]),
     "idf_layernorm": (ci, [vp, ci, vp, ci, vp, vp, ci, ci, cf, ci, vp]),
+    "idf_row_stats": (ci, [vp, ci, vp, ci, ci, cf, ci, vp]),
     "idf_layernorm_patch2": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, cf, ci, vp]),
     "idf_seg_in_conv": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "idf_dwconv7x7": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
@@ -93,7 +97,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.idf_abi_version() != 1:
+    if lib.idf_abi_version() != 2:
         raise RuntimeError("libidf_gfx950.so ABI version mismatch")
     _lib = lib
     return lib

@@ -230,20 +230,37 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
         static_for<0, TN, 2>([&](auto AI) {
           constexpr int a = decltype(AI)::value;
           const int npk = nw + a * 32;                    // packed weight rows: [32 value | 32 gate]
-          f32x4 bv[4], bg[4];
+          f32x4 bv[4], bg[4], cv[4], cg[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             bv[q] = *reinterpret_cast<const f32x4*>(p.bias + npk + 8 * q + 4 * hi);
             bg[q] = *reinterpret_cast<const f32x4*>(p.bias + npk + 32 + 8 * q + 4 * hi);
+            if (epi & IDF_EPI_LN_ROW) {
+              cv[q] = *reinterpret_cast<const f32x4*>(p.ln_c + npk + 8 * q + 4 * hi);
+              cg[q] = *reinterpret_cast<const f32x4*>(p.ln_c + npk + 32 + 8 * q + 4 * hi);
+            }
           }
 #pragma unroll
           for (int b = 0; b < TM; ++b) {
             f32x16 o;
+            if (epi & IDF_EPI_LN_ROW) {               // LayerNorm folded in: rstd * (acc - mu * c) + (beta term + bias)
+              const int mr = min(mw + b * 32 + l31, p.M - 1);
+              const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)mr);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float val = fmaf(st[1], fmaf(-st[0], cv[q][e], acc[a][b][4 * q + e]), bv[q][e]);
+                  const float gat = fmaf(st[1], fmaf(-st[0], cg[q][e], acc[a + 1][b][4 * q + e]), bg[q][e]);
+                  o[4 * q + e] = val * gelu_erf_f(gat);
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 o[4 * q + e] = (acc[a][b][4 * q + e] + bv[q][e]) * gelu_erf_f(acc[a + 1][b][4 * q + e] + bg[q][e]);
+            }
             float v[16];
             swap16(o, v);
             const int m = mw + b * 32 + l31;
@@ -259,10 +276,14 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
       static_for<0, TN, 1>([&](auto AI) {
         constexpr int a = decltype(AI)::value;
         const int n = nw + a * 32 + 16 * hi;
-        f32x4 bs[4];
+        f32x4 bs[4], cs[4];
         if (epi & IDF_EPI_BIAS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) bs[j] = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * j);
+        }
+        if (epi & IDF_EPI_LN_ROW) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cs[j] = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * j);
         }
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
@@ -270,6 +291,21 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
           swap16(acc[a][b], v);
           const int m = mw + b * 32 + l31;
           if (m >= p.M) continue;
+          if (epi & IDF_EPI_LN_ROW) {                 // v = rstd_m * (acc - mu_m * c[n]); the beta term arrives as bias
+            const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)m);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = st[1] * fmaf(-st[0], cs[j >> 2][j & 3], v[j]);
+          }
+          if (epi & IDF_EPI_LN_COL) {                 // v = rstd_n * (acc - c[m] * mu_n) + d[m]: 16 token columns of row m
+            const float cm = p.ln_c[m], dm = p.ln_d[m];
+            const f32x4* st4 = reinterpret_cast<const f32x4*>(p.ln_stats + 2 * (size_t)n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const f32x4 t = st4[j];                   // (mu, rstd) of tokens n + 2j, n + 2j + 1
+              v[2 * j] = fmaf(t[1], fmaf(-cm, t[0], v[2 * j]), dm);
+              v[2 * j + 1] = fmaf(t[3], fmaf(-cm, t[2], v[2 * j + 1]), dm);
+            }
+          }
           if (epi & IDF_EPI_BIAS) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] += bs[j >> 2][j & 3];
@@ -366,6 +402,7 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if ((p.ldo % 8) || ((p.epi & IDF_EPI_RES) && (p.ldr % 8)) || ((p.epi & IDF_EPI_ROWBIAS) && (p.ld_rowbias % 8))) return IDF_BIG_UNSUPPORTED;
   if (!aligned16(p.out) || ((p.epi & IDF_EPI_RES) && !aligned16(p.res)) || ((p.epi & IDF_EPI_ROWBIAS) && !aligned16(p.rowbias)) ||
       ((p.epi & (IDF_EPI_BIAS | IDF_EPI_GEGLU)) && !aligned16(p.bias))) return IDF_BIG_UNSUPPORTED;
+  if ((p.epi & (IDF_EPI_LN_ROW | IDF_EPI_LN_COL)) && (!aligned16(p.ln_c) || !aligned16(p.ln_stats))) return IDF_BIG_UNSUPPORTED;
   int bn = 0;
   if (geglu) bn = (p.N % 256 == 0) ? 256 : 0;
   else if (p.N % 320 == 0) bn = 320;

@@ -72,6 +72,14 @@ __device__ __forceinline__ void tile_epilogue(const CoreParams& p, f32x16 (&acc)
           *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(src + 36);
           const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + npk), bv1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 4);
           const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + npk + 32), bg1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 36);
+          if (epi & IDF_EPI_LN_ROW) {                            // LayerNorm folded in (gemm_core.h epilogue8 has the plain form)
+            const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + (size_t)bz * p.stride_ln_stats + 2 * (size_t)m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] = st[1] * fmaf(-st[0], p.ln_c[npk + e], v[e]);
+              g[e] = st[1] * fmaf(-st[0], p.ln_c[npk + 32 + e], g[e]);
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[e] = (v[e] + bv0[e]) * gelu_erf_f(g[e] + bg0[e]);
@@ -632,10 +640,26 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   p.gate = a->gate; p.epi = a->epi; p.n_valid = a->N;
   p.ws = (float*)a->ws; p.ws_bytes = a->ws ? (size_t)a->ws_bytes : 0;
   const int batch = a->batch > 0 ? a->batch : 1;
+  if (a->epi & (IDF_EPI_LN_ROW | IDF_EPI_LN_COL)) {
+    if ((a->epi & IDF_EPI_LN_ROW) && (a->epi & IDF_EPI_LN_COL)) return IDF_E_ARG;
+    if (!a->ln_stats || !a->ln_c) return IDF_E_ARG;
+    if ((a->epi & IDF_EPI_LN_ROW) && !(a->epi & IDF_EPI_BIAS)) return IDF_E_ARG;       // the beta term travels as bias
+    if ((a->epi & IDF_EPI_LN_COL) && (!a->ln_d || (a->epi & IDF_EPI_GEGLU))) return IDF_E_ARG;
+    if ((((uintptr_t)a->ln_stats) & 7u) || (a->stride_ln_stats & 1)) return IDF_E_ALIGN;
+    p.ln_stats = a->ln_stats; p.stride_ln_stats = a->stride_ln_stats; p.ln_c = a->ln_c; p.ln_d = a->ln_d;
+  }
+  if (a->out_stats) {
+    // by-product for a LayerNorm that follows: (mu, rstd) of every output row -- 16-bit row-major output only
+    if ((a->epi & (IDF_EPI_GEGLU | IDF_EPI_OUT_F32)) || (a->N % 8) || a->N > 1536 || (a->ldo % 8)) return IDF_E_ARG;
+    if (batch > 1 && a->strideO != (long long)a->M * a->ldo) return IDF_E_ARG;          // rows of all batches must be ld-regular
+  }
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == IDF_BF16) return launch<IDF_BF16, false>(p, batch, s);
-  if (a->dtype == IDF_F16) return launch<IDF_F16, false>(p, batch, s);
-  return IDF_E_UNSUPPORTED;
+  int rc = IDF_E_UNSUPPORTED;
+  if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p, batch, s);
+  else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p, batch, s);
+  if (rc == 0 && a->out_stats)
+    rc = idf_row_stats(a->out, a->ldo, a->out_stats, batch * a->M, a->N, a->out_stats_eps, a->dtype, stream);
+  return rc;
 }
 
 extern "C" int idf_conv3x3(const idf_conv3x3_args* a, void* stream) {

@@ -14,6 +14,9 @@ struct CoreParams {
   const unsigned short* res; int ldr; long long strideR;
   const float* gate; int epi; int n_valid;
   float* ws; size_t ws_bytes; int splitk; int kt_per_slice;   // split-K: fp32 partial slabs ws[slice][M][N]
+  // LayerNorm folded into the GEMM (IDF_EPI_LN_ROW / IDF_EPI_LN_COL, include/idf.h): (mu, rstd) pairs of the normalised
+  // operand's rows, the column sums c of the gamma-folded weight and (LN_COL) the beta term d
+  const float* ln_stats; long long stride_ln_stats; const float* ln_c; const float* ln_d;
 };
 
 constexpr int BK = 64;
@@ -25,6 +28,17 @@ template <int DT>
 __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, int n, float* v, float gate) {
   const int epi = p.epi;
   const bool full = (n + 7 < p.N);
+  if (epi & IDF_EPI_LN_ROW) {                       // v = rstd_m * (acc - mu_m * c[n]); the beta term arrives as bias
+    const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + (size_t)bz * p.stride_ln_stats + 2 * (size_t)m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] = st[1] * fmaf(-st[0], p.ln_c[n + e], v[e]);
+  }
+  if (epi & IDF_EPI_LN_COL) {                       // v = rstd_n * (acc - c[m] * mu_n) + d[m]
+    const float cm = p.ln_c[m], dm = p.ln_d[m];
+    const float* st = p.ln_stats + (size_t)bz * p.stride_ln_stats + 2 * (size_t)n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] = fmaf(st[2 * e + 1], fmaf(-cm, st[2 * e], v[e]), dm);
+  }
   if (epi & IDF_EPI_BIAS) {
     if (full) {
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);

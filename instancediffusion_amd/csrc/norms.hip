@@ -244,6 +244,58 @@ extern "C" int idf_layernorm(const void* x, int ldx, void* out, int ldo, const f
   return idf_launch_status();
 }
 
+// Row statistics for a LayerNorm folded into the consumer GEMM (IDF_EPI_LN_ROW / IDF_EPI_LN_COL): one wave64 per row, the
+// row in registers, exact two-pass like ln_kernel -- but nothing is written except (mu, rstd): half of LayerNorm's HBM
+// traffic, and the normalised matrix is never re-read.
+template <int DT>
+__global__ __launch_bounds__(256) void row_stats_kernel(const unsigned short* __restrict__ x, int ldx, float* __restrict__ stats,
+                                                       int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cpr = C >> 3;
+  const unsigned short* xr = x + (size_t)row * ldx;
+  float f[3][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cpr) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      unpack8<DT>(v, f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cpr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dlt = f[i][j] - mu; q = fmaf(dlt, dlt, q); }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (size_t)row) = f32x2{mu, rs};
+}
+
+extern "C" int idf_row_stats(const void* x, int ldx, float* stats, int M, int C, float eps, int dtype, void* stream) {
+  if (!x || !stats) return IDF_E_ARG;
+  if (M <= 0 || C <= 0 || (C % 8) || C > 1536) return IDF_E_ARG;
+  if ((ldx % 8) || !aligned16(x) || (((uintptr_t)stats) & 7u)) return IDF_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((M + 3) / 4);
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(row_stats_kernel<IDF_BF16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, stats, M, C, eps);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(row_stats_kernel<IDF_F16>, grid, dim3(256), 0, s, (const unsigned short*)x, ldx, stats, M, C, eps);
+  else return IDF_E_UNSUPPORTED;
+  return idf_launch_status();
+}
+
 extern "C" int idf_layernorm_patch2(const void* x, void* out, int ldo, const float* gamma, const float* beta,
                                     int B, int H, int W, int C, float eps, int dtype, void* stream) {
   if (!x || !out || !gamma || !beta) return IDF_E_ARG;

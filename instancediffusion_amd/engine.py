@@ -150,16 +150,39 @@ class UNetEngine:
     def _conv(self, m) -> _Lin:
         return _Lin(self._w16(pack_conv3x3(m.weight.detach().float())), self._f32(m.bias))
 
-    def _pack_ff(self, ff):
-        w, b = pack_geglu(ff.net[0].proj.weight.detach().float(), ff.net[0].proj.bias.detach().float())
-        return dict(w1=self._w16(w), b1=self._f32(b), l2=self._lin(ff.net[2]))
+    # LayerNorm -> Linear pairs are stored FOLDED (include/idf.h IDF_EPI_LN_ROW / LN_COL): the weight carries gamma,
+    #   LN(x) W^T = rstd * (x (gamma*W)^T - mu * c) + d,   c = row sums of the 16-bit (gamma*W),   d = W beta (+ bias),
+    # so the forward never materialises LN(x): a GEMM reads the raw residual stream and its epilogue applies (mu, rstd).
+    def _fold_ln(self, w: torch.Tensor, bias, norm):
+        """-> (16-bit gamma-folded weight, c [N] fp32 = its row sums as the MFMA sees them, d [N] fp32 = W beta + bias)."""
+        w = w.detach().float()
+        g, b = norm.weight.detach().float(), norm.bias.detach().float()
+        w16 = self._w16(w * g[None, :])
+        d = w @ b + (bias.detach().float() if bias is not None else 0.0)
+        return w16, w16.float().sum(1).contiguous(), self._f32(d)
 
-    def _attn(self, a, fuse_qk: bool):
-        d = dict(wv=self._w16(a.to_v.weight), wk=self._w16(a.to_k.weight), wq=self._w16(a.to_q.weight),
-                 out=self._lin(a.to_out[0]))
-        if fuse_qk:
-            d["wqk"] = self._w16(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach()], 0))
+    def _pack_ff(self, ff, norm):
+        """GEGLU feed-forward behind LayerNorm `norm`: proj rows interleaved [32 value | 32 gate] (pack_geglu), gamma folded."""
+        w = ff.net[0].proj.weight.detach().float()
+        g, b = norm.weight.detach().float(), norm.bias.detach().float()
+        wp, dp = pack_geglu(w * g[None, :], ff.net[0].proj.bias.detach().float() + w @ b)
+        w16 = self._w16(wp)
+        return dict(w1=w16, b1=self._f32(dp), c1=w16.float().sum(1).contiguous(), l2=self._lin(ff.net[2]))
+
+    def _attn(self, a, norm, self_attn: bool):
+        """Attention projections behind LayerNorm `norm` (applied to the QUERY side input; for self-attention also to K / V)."""
+        d = dict(out=self._lin(a.to_out[0]))
+        if self_attn:
+            d["wqk"], d["cqk"], d["dqk"] = self._fold_ln(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach()], 0), None, norm)
+            d["wv"], d["cv"], d["dv"] = self._fold_ln(a.to_v.weight, None, norm)
+        else:                                        # cross attention: K / V come from the (un-normalised) text context
+            d["wq"], d["cq"], d["dq"] = self._fold_ln(a.to_q.weight, None, norm)
+            d["wk"], d["wv"] = self._w16(a.to_k.weight), self._w16(a.to_v.weight)
         return d
+
+    def _attn_kv_plain(self, a):
+        """K / V projections of the fuser for the grounding-token rows (their LayerNorm runs once per conditioning)."""
+        return dict(wk=self._w16(a.to_k.weight), wv=self._w16(a.to_v.weight))
 
     def _pack_res(self, rb: ResBlock, emb_w: list, emb_b: list, off: list):
         p = dict(kind="res", cin=rb.channels, cout=rb.out_channels,
@@ -186,8 +209,10 @@ class UNetEngine:
                     n1=(self._f32(blk.norm1.weight), self._f32(blk.norm1.bias)),
                     n2=(self._f32(blk.norm2.weight), self._f32(blk.norm2.bias)),
                     n3=(self._f32(blk.norm3.weight), self._f32(blk.norm3.bias)),
-                    attn1=self._attn(blk.attn1, True), attn2=self._attn(blk.attn2, False), ff=self._pack_ff(blk.ff),
-                    f_lin=self._lin(fz.linear), f_attn=self._attn(fz.attn, True), f_ff=self._pack_ff(fz.ff),
+                    attn1=self._attn(blk.attn1, blk.norm1, True), attn2=self._attn(blk.attn2, blk.norm2, False),
+                    ff=self._pack_ff(blk.ff, blk.norm3),
+                    f_lin=self._lin(fz.linear), f_attn=self._attn(fz.attn, fz.norm1, True), f_kv=self._attn_kv_plain(fz.attn),
+                    f_ff=self._pack_ff(fz.ff, fz.norm2),
                     f_n1=(self._f32(fz.norm1.weight), self._f32(fz.norm1.bias)),
                     f_n2=(self._f32(fz.norm2.weight), self._f32(fz.norm2.bias)))
 
@@ -449,7 +474,7 @@ class UNetEngine:
         ld_ctx, ld_obj = _round_up(n_ctx, 64), _round_up(OBJ_TOKENS, 64)
         for p in self._st_layers():
             C = p["c"]
-            a2, fa = p["attn2"], p["f_attn"]
+            a2, fa = p["attn2"], p["f_kv"]
             k = ops.gemm(ctx16.view(B * n_ctx, cd), a2["wk"], ops.empty((B * n_ctx, C))).view(B, n_ctx, C)
             vt = ops.zeros((B, C, ld_ctx))
             ops.gemm(a2["wv"], ctx16, vt[:, :, :n_ctx])
@@ -482,23 +507,24 @@ class UNetEngine:
             xs = x
         return ops.conv3x3(g2, p["conv2"].w, self.buf(out_role, (B, H, W, Cout)), bias=p["conv2"].b, res=xs)
 
-    def _self_attn(self, a, x2, ln, B, N, C, kv_extra=None, vis=None):
-        """x2 [B*N, C] residual stream, ln = LayerNorm(x2).  Returns the attention output [B, N, C] (pre out-proj).
+    def _self_attn(self, a, y, st, B, N, C, kv_extra=None, vis=None):
+        """y [B*N, C] residual stream (raw), st [B*N, 2] its LayerNorm statistics (mu, rstd); the LayerNorm itself is folded
+        into the projections (``_fold_ln``).  Returns the attention output [B, N, C] (pre out-proj).
         ``vis``: (qbits, kbits0, kbits1) visibility words of the masked gated self-attention, or None."""
         ops = self.ops
-        qk = ops.gemm(ln, a["wqk"], self.buf("st.qk", (B * N, 2 * C))).view(B, N, 2 * C)
+        qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(st, a["cqk"])).view(B, N, 2 * C)
         if self.vt_global and N % 64 == 0 and N >= 1024:
             # V^T in the batch-interleaved image [C][B][N]: ONE unbatched GEMM  V^T = Wv . X^T  over all B*N tokens
             # (M = C, N = B*N: served by the persistent big-tile kernel) instead of B small batched ones; the
             # attention kernel reads sample b through (base + b*N, ld = B*N) -- no kernel change, no extra copy.
             # Measured at 64 rows (profiles/r01_vt_gemm_ab.log): C=320/N=4096 174 -> 114 us, C=640/N=1024 102 -> 89 us,
             # bitwise-equal output; at N=256 the batched form is 5 % faster, hence the N >= 1024 gate.
-            vtg = ops.gemm(a["wv"], ln, self.buf("st.vtg", (C, B * N)))
+            vtg = ops.gemm(a["wv"], y, self.buf("st.vtg", (C, B * N)), ln_col=(st, a["cv"], a["dv"]))
             vt = vtg.view(C, B, N).permute(1, 0, 2)
         else:
             ldv = _round_up(N, 64)
             vt = self.buf("st.vt", (B, C, ldv), zero=True)
-            ops.gemm(a["wv"], ln.view(B, N, C), vt[:, :, :N])
+            ops.gemm(a["wv"], y.view(B, N, C), vt[:, :, :N], ln_col=(st.view(B, N, 2), a["cv"], a["dv"]))
         att = self.buf("st.att", (B, N, C))
         if kv_extra is None:
             ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads)
@@ -510,41 +536,41 @@ class UNetEngine:
                           n1=OBJ_TOKENS, qbits=vis[0], kbits0=vis[1], kbits1=vis[2])
         return att
 
-    def _ff(self, f, x2, ln, M, C, gate=None):
+    def _ff(self, f, y, st, M, C, gate=None, out_stats=None):
+        """y += [gate *] GEGLU-FF(LN(y)); the LayerNorm is folded into the first GEMM (statistics st)."""
         ops = self.ops
-        mid = ops.gemm(ln, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True)
-        return ops.gemm(mid, f["l2"].w, x2, bias=f["l2"].b, res=x2, gate=gate)
+        mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True, ln_row=(st, f["c1"]))
+        return ops.gemm(mid, f["l2"].w, y, bias=f["l2"].b, res=y, gate=gate, out_stats=out_stats)
 
     def _st(self, p, x, cond: Cond, fuser_on: bool):
+        """SpatialTransformer (attention.py:366-379).  No LayerNorm kernel runs: every GEMM that writes the residual stream y
+        also emits (mu, rstd) of its output rows (``out_stats``) and every GEMM that reads LN(y) reads y itself and applies
+        them in its epilogue against gamma-folded weights."""
         ops = self.ops
         B, H, W, C = x.shape
         N, M = H * W, B * H * W
         g = ops.groupnorm(x, self.buf("gn", x.shape), p["norm"][0], p["norm"][1], 1e-6, False)
-        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b)
-        lnb = self.buf("st.ln", (M, C))
-        # --- self attention (attention.py:334)
-        ln = ops.layernorm(y, lnb, *p["n1"])
-        att = self._self_attn(p["attn1"], y, ln, B, N, C)
-        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y)
-        # --- gated self attention over [visual ; grounding tokens] (attention.py:304-311)
-        if fuser_on:
-            i = p["idx"]
-            ln = ops.layernorm(y, lnb, *p["f_n1"])
-            vis = cond.vis if (cond.vis and N == MASK_RES * MASK_RES) else None
-            att = self._self_attn(p["f_attn"], y, ln, B, N, C, kv_extra=(cond.k_obj[i], cond.vt_obj[i]), vis=vis)
-            ops.gemm(att.view(M, C), p["f_attn"]["out"].w, y, bias=p["f_attn"]["out"].b, res=y, gate=self.gates[i, 0:1])
-            ln = ops.layernorm(y, lnb, *p["f_n2"])
-            self._ff(p["f_ff"], y, ln, M, C, gate=self.gates[i, 1:2])
-        # --- cross attention (attention.py:336)
+        st = self.buf("st.stats", (M, 2), torch.float32)
+        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b, out_stats=st)
+        # --- self attention (attention.py:334): LN norm1
+        att = self._self_attn(p["attn1"], y, st, B, N, C)
+        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y, out_stats=st)
+        # --- gated self attention over [visual ; grounding tokens] (attention.py:304-311): LN fuser.norm1 / norm2
         i = p["idx"]
-        ln = ops.layernorm(y, lnb, *p["n2"])
-        q = ops.gemm(ln, p["attn2"]["wq"], self.buf("st.q", (M, C))).view(B, N, C)
+        if fuser_on:
+            vis = cond.vis if (cond.vis and N == MASK_RES * MASK_RES) else None
+            att = self._self_attn(p["f_attn"], y, st, B, N, C, kv_extra=(cond.k_obj[i], cond.vt_obj[i]), vis=vis)
+            ops.gemm(att.view(M, C), p["f_attn"]["out"].w, y, bias=p["f_attn"]["out"].b, res=y, gate=self.gates[i, 0:1],
+                     out_stats=st)
+            self._ff(p["f_ff"], y, st, M, C, gate=self.gates[i, 1:2], out_stats=st)
+        # --- cross attention (attention.py:336): LN norm2 on the query side
+        a2 = p["attn2"]
+        q = ops.gemm(y, a2["wq"], self.buf("st.q", (M, C)), bias=a2["dq"], ln_row=(st, a2["cq"])).view(B, N, C)
         att = self.buf("st.att", (B, N, C))
         ops.attention(q, cond.k_ctx[i], cond.vt_ctx[i], cond.n_ctx, att, self.heads)
-        ops.gemm(att.view(M, C), p["attn2"]["out"].w, y, bias=p["attn2"]["out"].b, res=y)
-        # --- feed forward (attention.py:337)
-        ln = ops.layernorm(y, lnb, *p["n3"])
-        self._ff(p["ff"], y, ln, M, C)
+        ops.gemm(att.view(M, C), a2["out"].w, y, bias=a2["out"].b, res=y, out_stats=st)
+        # --- feed forward (attention.py:337): LN norm3
+        self._ff(p["ff"], y, st, M, C)
         # --- proj_out + x_in (attention.py:378-379), in place on the block input
         ops.gemm(y, p["proj_out"].w, x.view(M, C), bias=p["proj_out"].b, res=x.view(M, C))
         return x

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GATE, EPI_GEGLU, EPI_GELU, EPI_OUT_F32, EPI_OUT_NCHW, EPI_RES, EPI_ROWBIAS, EPI_SILU)
+from ._lib import (EPI_BIAS, EPI_GATE, EPI_GEGLU, EPI_GELU, EPI_LN_COL, EPI_LN_ROW, EPI_OUT_F32, EPI_OUT_NCHW, EPI_RES,
+                   EPI_ROWBIAS, EPI_SILU)
 
 _DT = {torch.bfloat16: _lib.IDF_BF16, torch.float16: _lib.IDF_F16}
 
@@ -66,9 +67,13 @@ class HipOps:
 
     # ------------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None,
-             act: Optional[str] = None, geglu: bool = False):
+             act: Optional[str] = None, geglu: bool = False, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5):
         """out[..,M,N] = epi(a[..,M,K] @ w[..,N,K]^T).  2-D or batched 3-D views; a/w may be shared (2-D) in a
-        batched call.  geglu: ``w``/``bias`` are in the packed [32 value | 32 gate] row order, out has N/2 cols."""
+        batched call.  geglu: ``w``/``bias`` are in the packed [32 value | 32 gate] row order, out has N/2 cols.
+        ln_row = (stats [.., M, 2], c [N]): ``a`` is the RAW input of a LayerNorm whose gamma is folded into ``w`` and whose
+        beta term travels in ``bias`` (include/idf.h IDF_EPI_LN_ROW).  ln_col = (stats [.., N, 2], c [M], d [M]): the same
+        with the normalised operand on the ``w`` side (transposed-V projection).  out_stats [.., M, 2]: also emit (mu, rstd)
+        of every output row for a LayerNorm that follows."""
         batched = out.dim() == 3
         M, K = a.shape[-2], a.shape[-1]
         N = w.shape[-2]
@@ -100,6 +105,21 @@ class HipOps:
             assert out.shape[-1] == N and out.shape[-2] == M
         if out.dtype == torch.float32:
             epi |= EPI_OUT_F32
+        ln_stats = ln_c = ln_d = None
+        s_ln = 0
+        if ln_row is not None:
+            ln_stats, ln_c = ln_row
+            assert bias is not None and ln_stats.shape[-2] == M and ln_c.numel() == N and ln_stats.dtype == torch.float32
+            epi |= EPI_LN_ROW
+        elif ln_col is not None:
+            ln_stats, ln_c, ln_d = ln_col
+            assert ln_stats.shape[-2] == N and ln_c.numel() == M and ln_d.numel() == M and ln_stats.dtype == torch.float32
+            epi |= EPI_LN_COL
+        if ln_stats is not None:
+            assert ln_stats.is_contiguous() and ln_stats.shape[-1] == 2
+            s_ln = ln_stats.stride(0) if (batched and ln_stats.dim() == 3) else 0
+        if out_stats is not None:
+            assert out_stats.is_contiguous() and out_stats.dtype == torch.float32 and out_stats.numel() == 2 * out.numel() // N
         args = _lib.GemmArgs(
             A=a.data_ptr(), W=w.data_ptr(), out=out.data_ptr(),
             bias=None if bias is None else bias.data_ptr(),
@@ -109,7 +129,10 @@ class HipOps:
             M=M, N=N, K=K, lda=lda, ldw=ldw, ldo=ldo, ldr=ldr,
             ld_rowbias=0 if rowbias is None else rowbias.stride(-2), rows_per_batch=rows_per_batch,
             batch=out.shape[0] if batched else 1, strideA=sA, strideW=sW, strideO=sO, strideR=sR,
-            epi=epi, dtype=self.dt, ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES)
+            epi=epi, dtype=self.dt, ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES,
+            ln_stats=None if ln_stats is None else ln_stats.data_ptr(), stride_ln_stats=s_ln,
+            ln_c=None if ln_c is None else ln_c.data_ptr(), ln_d=None if ln_d is None else ln_d.data_ptr(),
+            out_stats=None if out_stats is None else out_stats.data_ptr(), out_stats_eps=float(out_stats_eps))
         _lib.check(self.lib.idf_gemm(C.byref(args), self._stream()), "idf_gemm")
         return out
 
@@ -192,6 +215,15 @@ class HipOps:
         _lib.check(self.lib.idf_layernorm(_p(x), x.stride(0), _p(out), out.stride(0), _p(gamma), _p(beta), M, Cc,
                                           float(eps), self.dt, self._stream()), "idf_layernorm")
         return out
+
+    def row_stats(self, x, stats, eps=1e-5):
+        """stats[m] = (mean, rstd) of row m of x [M, C] (fp32 [M, 2]): the LayerNorm statistics a following gemm(ln_row /
+        ln_col) applies in its epilogue."""
+        M, Cc = x.shape
+        assert stats.is_contiguous() and stats.dtype == torch.float32 and stats.numel() == 2 * M
+        _lib.check(self.lib.idf_row_stats(_p(x), x.stride(0), _p(stats), M, Cc, float(eps), self.dt, self._stream()),
+                   "idf_row_stats")
+        return stats
 
     def layernorm_patch2(self, x, out, gamma, beta, eps):
         """x [B,H,W,C] contiguous; out [B*(H/2)*(W/2), >=4C] rows in 2x2 patch order."""

@@ -35,11 +35,19 @@ class EmulOps:
         return torch.zeros(shape, dtype=dtype or self.dtype)
 
     # ----------------------------------------------------------------------------------------------
-    def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None, act=None, geglu=False):
+    def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None, act=None, geglu=False,
+             ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5):
         self._count("gemm")
         assert a.dtype == self.dtype and w.dtype == self.dtype
         assert a.shape[-1] % 64 == 0, "K % 64"
         acc = torch.matmul(a.float(), w.float().transpose(-1, -2))
+        if ln_row is not None:                         # include/idf.h IDF_EPI_LN_ROW: rstd_m * (acc - mu_m c_n) (+ d as bias)
+            st, c = ln_row
+            assert bias is not None
+            acc = st[..., 1:2] * (acc - st[..., 0:1] * c.reshape(1, -1))
+        if ln_col is not None:                         # IDF_EPI_LN_COL: rstd_n * (acc - c_m mu_n) + d_m
+            st, c, d = ln_col
+            acc = st[..., 1].unsqueeze(-2) * (acc - c.reshape(-1, 1) * st[..., 0].unsqueeze(-2)) + d.reshape(-1, 1)
         if geglu:
             n2 = acc.shape[-1]
             acc = acc + bias
@@ -61,6 +69,11 @@ class EmulOps:
             r = res.float()
             acc = r + (gate.float() * acc if gate is not None else acc)
         out.copy_(acc)
+        if out_stats is not None:                      # (mu, rstd) of the 16-bit-rounded output rows
+            o = out.float().reshape(-1, out.shape[-1])
+            mu = o.mean(-1)
+            out_stats.reshape(-1, 2)[:, 0] = mu
+            out_stats.reshape(-1, 2)[:, 1] = torch.rsqrt(o.var(-1, unbiased=False) + out_stats_eps)
         return out
 
     def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
@@ -140,6 +153,13 @@ class EmulOps:
         self._count("layernorm")
         out.copy_(F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps))
         return out
+
+    def row_stats(self, x, stats, eps=1e-5):
+        self._count("row_stats")
+        xf = x.float()
+        stats.reshape(-1, 2)[:, 0] = xf.mean(-1)
+        stats.reshape(-1, 2)[:, 1] = torch.rsqrt(xf.var(-1, unbiased=False) + eps)
+        return stats
 
     def layernorm_patch2(self, x, out, gamma, beta, eps):
         self._count("layernorm_patch2")

@@ -3,6 +3,8 @@ caches and two-segment attention bookkeeping are exercised against the CPU oracl
 CPU op emulation in tests/emul_ops.py.  With fp32 storage the engine must agree with the reference to fp32 round-off;
 with bf16 storage the error shows what to expect from the MI355X kernels.
 """
+import os
+
 import pytest
 import torch
 
@@ -23,10 +25,19 @@ def build_model(cfg, efficient_attention=True):
     return m.eval()
 
 
+# The default CPU suite keeps the fp32 runs of the four reduced-width configurations (every host-logic branch: packing,
+# LayerNorm folding, Cond caches, batching) within a few minutes; the real-width "mid" model and the bf16 STORAGE emulations
+# (CPU bf16 matmuls: 1.5 - 3 min each) only predict what the GPU parity tests measure directly and run with IDF_FULL_CPU_SUITE=1.
+FULL = os.environ.get("IDF_FULL_CPU_SUITE") == "1"
+heavy = pytest.mark.skipif(not FULL, reason="heavy CPU emulation: set IDF_FULL_CPU_SUITE=1 (the GPU parity tests cover it)")
+
+
 @pytest.mark.parametrize("tag,dtype,tol", [
-    ("tiny_box", torch.float32, 3e-4), ("tiny_point", torch.float32, 3e-4), ("mid_box", torch.float32, 3e-4),
-    ("tiny_mask", torch.float32, 3e-4), ("tiny_scribble", torch.float32, 3e-4), ("tiny_mask", torch.bfloat16, 4e-2),
-    ("tiny_box", torch.bfloat16, 4e-2), ("mid_box", torch.bfloat16, 4e-2),
+    ("tiny_box", torch.float32, 3e-4), ("tiny_point", torch.float32, 3e-4),
+    pytest.param("mid_box", torch.float32, 3e-4, marks=heavy),
+    ("tiny_mask", torch.float32, 3e-4), ("tiny_scribble", torch.float32, 3e-4),
+    pytest.param("tiny_mask", torch.bfloat16, 4e-2, marks=heavy), pytest.param("tiny_box", torch.bfloat16, 4e-2, marks=heavy),
+    pytest.param("mid_box", torch.bfloat16, 4e-2, marks=heavy),
 ])
 def test_engine_forward_vs_reference(tag, dtype, tol):
     gold = cases.load_golden(tag)

@@ -548,6 +548,77 @@ def test_attention_v2_matches_v1(ops, attn2):
     assert relmax(o2, o1) < BF16_TOL
 
 
+# ---------------------------------------------------------------------------------------------------
+# LayerNorm folded into the GEMM epilogue (IDF_EPI_LN_ROW / IDF_EPI_LN_COL) + row statistics
+# ---------------------------------------------------------------------------------------------------
+def _fold(w, gamma, beta, bias=None):
+    """engine._fold_ln: (16-bit gamma-folded weight, its row sums c, d = W beta + bias)."""
+    w16 = to16(w * gamma[None, :])
+    return w16, w16.float().sum(1), w @ beta + (bias if bias is not None else 0.0)
+
+
+@pytest.mark.parametrize("M,C", [(4096, 320), (1000, 640), (77, 1280), (5, 64)])
+def test_row_stats(ops, M, C):
+    x = to16(gen((M, C), 80) * 2 + 0.7)
+    st = ops.row_stats(dev(x), ops.empty((M, 2), torch.float32), 1e-5)
+    torch.cuda.synchronize()
+    xf = x.float()
+    assert torch.allclose(st[:, 0].cpu(), xf.mean(-1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(st[:, 1].cpu(), torch.rsqrt(xf.var(-1, unbiased=False) + 1e-5), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [
+    (65536, 640, 320, "row"), (65536, 320, 320, "row"), (300, 640, 320, "row"), (4096, 1280, 640, "row"),      # big / fallback
+    (65536, 2560, 320, "geglu"), (200, 2560, 320, "geglu"),
+    (320, 65536, 320, "col"), (320, 200, 320, "col"), (640, 4096, 640, "col")])
+def test_gemm_layernorm_folded(ops, M, N, K, mode):
+    """out = LN(x) W^T computed as rstd * (x (gamma W)^T - mu c) + d in the GEMM epilogue (attention.py:294-295,320-322),
+    against the fp32 reference LayerNorm -> Linear on the same 16-bit x; the explicit LN -> 16-bit -> GEMM path the engine
+    used before is one 16-bit rounding WORSE than this, so the old kernel tolerance applies unchanged."""
+    import torch.nn.functional as F
+    from instancediffusion_amd.engine import pack_geglu
+    gamma, beta = 1 + 0.2 * gen((K,), 81), 0.3 * gen((K,), 82)
+    if mode == "col":                                   # the normalised operand is the N-side one (tokens), A = weight
+        xw = to16(gen((N, K), 83) * 1.5 + 0.4)
+        wa = gen((M, K), 84, K ** -0.5)
+        w16, c, d = _fold(wa, gamma, beta)
+        st = ops.row_stats(dev(xw), ops.empty((N, 2), torch.float32), 1e-5)
+        out = ops.gemm(dev(w16), dev(xw), ops.empty((M, N)), ln_col=(st, dev(c), dev(d)))
+        want = (F.layer_norm(xw.float(), (K,), gamma, beta, 1e-5) @ wa.t()).t()
+    else:
+        x = to16(gen((M, K), 83) * 1.5 + 0.4)
+        w, b = gen((N, K), 84, K ** -0.5), 0.2 * gen((N,), 85)
+        st = ops.row_stats(dev(x), ops.empty((M, 2), torch.float32), 1e-5)
+        ln = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+        if mode == "geglu":
+            wp, dp = pack_geglu(w * gamma[None, :], b + w @ beta)
+            w16 = to16(wp)
+            out = ops.gemm(dev(x), dev(w16), ops.empty((M, N // 2)), bias=dev(dp), geglu=True, ln_row=(st, dev(w16.float().sum(1))))
+            h = ln @ w.t() + b
+            want = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+        else:
+            w16, c, d = _fold(w, gamma, beta, b)
+            out = ops.gemm(dev(x), dev(w16), ops.empty((M, N)), bias=dev(d), ln_row=(st, dev(c)))
+            want = ln @ w.t() + b
+    torch.cuda.synchronize()
+    err, mx = rel_rms(out, want), relmax(out, want)
+    print(f"[parity] gemm LN-folded {mode} M{M} N{N} K{K}: rel-rms {err:.3e} max-rel {mx:.3e}")
+    assert mx < BF16_TOL and err < BF16_TOL / 2
+
+
+def test_gemm_out_stats(ops):
+    """The by-product (mu, rstd) of the OUTPUT rows equals the statistics of the 16-bit output actually written."""
+    M, N, K = 4096, 320, 320
+    a, w, b, r = to16(gen((M, K), 86)), to16(gen((N, K), 87, K ** -0.5)), gen((N,), 88), to16(gen((M, N), 89))
+    st = ops.empty((M, 2), torch.float32)
+    y = dev(r).clone()
+    ops.gemm(dev(a), dev(w), y, bias=dev(b), res=y, out_stats=st, out_stats_eps=1e-5)
+    torch.cuda.synchronize()
+    yf = y.float().cpu()
+    assert torch.allclose(st[:, 0].cpu(), yf.mean(-1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(st[:, 1].cpu(), torch.rsqrt(yf.var(-1, unbiased=False) + 1e-5), rtol=1e-5, atol=1e-6)
+
+
 def rel_rms(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float(((a - b).pow(2).mean() / b.pow(2).mean().clamp_min(1e-30)).sqrt())

@@ -51,7 +51,14 @@ def test_forward_matches_reference(tag):
                gold["eps_scale03"], FWD_TOL, "eps with fuser scale 0.3")
 
 
-@pytest.mark.parametrize("tag", ["tiny_box", "tiny_mask", "mid_box"])
+# heavy = minutes of CPU oracle time: opt-in (IDF_FULL_CPU_SUITE=1); the default suite still pins the S = 50 / N = 8 trajectory
+# shape on the reduced-width model and the C5 (point / scribble) trajectories
+import os
+heavy = pytest.mark.skipif(os.environ.get("IDF_FULL_CPU_SUITE") != "1", reason="minutes of CPU oracle time: set IDF_FULL_CPU_SUITE=1")
+
+
+@pytest.mark.parametrize("tag", ["tiny_box", "tiny_mask", "mid_box", "tiny_point_s5", "tiny_scribble_s5", "tiny_box_s50",
+                                 pytest.param("mid_box_s50", marks=heavy)])
 def test_samplers_match_reference(tag):
     gold, meta, cfg, sd, inp = _setup(tag)
     with torch.no_grad():
@@ -70,6 +77,16 @@ def test_samplers_match_reference(tag):
         out = ref_cpu.plms_sample_mis(model, meta["S"], inputs, inp["uc"], 7.5, meta["mis"],
                                       alpha_type=meta["alpha_type"])
         _check(out, gold["mis"], TRAJ_TOL, "MIS trajectory")
+
+
+@heavy
+def test_full_size_c4_forward_matches_reference():
+    """BASELINE config 4 at its stated size: test_mask.yaml, 96x96 latent, 12 masks with segs + polygons (ConvNeXt live)."""
+    gold, meta, cfg, sd, inp = _setup("full_mask_c4")
+    with torch.no_grad():
+        g = ref_cpu.prepare_grounding(inp["gb"])
+        objs, _ = ref_cpu.unifusion(sd, cfg, g)
+        _check(ref_cpu.unet_forward(sd, cfg, inp["x"], inp["t"], inp["context"], objs), gold["eps_cond"], FWD_TOL, "C4 eps_cond")
 
 
 @pytest.mark.slow

@@ -586,8 +586,18 @@ int launch(const CoreParams& p, int batch, hipStream_t s) {
   // quantisation heuristic), 2 forced whenever the shape qualifies.
   const int big = gemm_big_mode();
   if (big > 0 && batch == 1) {
-    const int rc = idf_launch_big(p, DT, CONV, big == 2, s);
-    if (rc != IDF_BIG_UNSUPPORTED) return rc;
+    int splitk = 1;
+    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk);
+    if (rc != IDF_BIG_UNSUPPORTED) {
+      if (rc == 0 && splitk > 1) {
+        CoreParams q = p;
+        q.splitk = splitk;
+        const size_t n8 = (size_t)q.M * ((q.N + 7) / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, q);
+        return idf_launch_status();
+      }
+      return rc;
+    }
   }
   // (64x64 tiles for short-K dense GEMMs were measured 6-20 % slower: profiles/r01_diag_B18_tile64_ab.log)
   if (geglu || (p.N % 128 == 0) || p.N > 1024 || (use_wide && p.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
@@ -604,7 +614,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
     return prev;
   }
   if (knob == IDF_TUNE_GEMM_GEOM) {
-    if (value < 0 || value > 1) return IDF_E_ARG;
+    if (value < 0 || value > 3) return IDF_E_ARG;
     return idf_big_set_geom(value);
   }
   if (knob == IDF_TUNE_ATTN2) {

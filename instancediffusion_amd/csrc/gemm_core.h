@@ -120,4 +120,5 @@ __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, in
 extern long long idf_stat_big_launches;
 int idf_big_geom();
 int idf_big_set_geom(int v);
-int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s);
+// *splitk_out > 1 on return: the kernel left fp32 partials of that many K-slices in p.ws; the caller runs the reducer
+int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out);

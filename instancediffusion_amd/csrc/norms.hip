@@ -1,8 +1,10 @@
 // norms.hip -- GroupNorm(32)+SiLU and LayerNorm for gfx950.  HBM-bandwidth-bound kernels:
 //   every global access is a 16-byte (8 x 16-bit) per-lane vector, fully coalesced on the NHWC / token-major layout;
 //   statistics are fp32 (the reference forces fp32 GroupNorm, util.py:223-226).
-// GroupNorm is two launches: (1) per-(batch, row-chunk) partial sums per group, deterministic fixed-order
-// reduction (no float atomics -> bitwise run-to-run reproducible); (2) finalize + normalise + affine (+SiLU).
+// GroupNorm is two launches: (1) per-(batch, row-chunk) partial (mean, M2) per group -- every thread accumulates its rows
+// SHIFTED by its first row's value (no E[x^2] - mu^2 cancellation however large |mean| / std is), partials are merged with
+// Chan's parallel-variance formula in a fixed order (no float atomics -> bitwise run-to-run reproducible);
+// (2) merge of the chunk partials in fp64 + normalise + affine (+SiLU).
 // Algorithmic bytes: 2 B read + 2 B written per element (the 2nd read of x is served by L2 / Infinity Cache for the
 // <= 100 MB activations of this UNet).
 #include "common.h"
@@ -19,11 +21,22 @@ __host__ __device__ inline int gn_nchunks(int HW) {
   return n;
 }
 
-// partial[b][chunk][g][2] = (sum, sumsq) over rows of the chunk
+// Chan et al. merge of two (count, mean, M2) summaries
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb;
+  const float d = mb - mean;
+  const float w = nb / nt;
+  mean = fmaf(d, w, mean);
+  m2 = m2 + m2b + d * d * n * w;
+  n = nt;
+}
+
+// partial[b][chunk][g][2] = (mean, M2) over the rows of the chunk (count = rows in the chunk x channels per group)
 template <int DT>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ partial,
                                                       int HW, int C, int nchunks) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];     // [2][TY][C]
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [3][TY][C]: count, mean, M2 per (row lane, channel)
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cpr = C >> 3;                                        // 16-B chunks per row
   const int TX = cpr < 256 ? cpr : 256;
@@ -34,32 +47,58 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __r
   const int r_begin = chunk * rows_per;
   const int r_end = min(HW, r_begin + rows_per);
   const unsigned short* xb = x + (size_t)b * HW * C;
-  float* s_sum = sm;
-  float* s_sq = sm + (size_t)TY * C;
+  float* s_n = sm;
+  float* s_mean = sm + (size_t)TY * C;
+  float* s_m2 = sm + 2 * (size_t)TY * C;
   if (ty < TY) {
     for (int cc = tx; cc < cpr; cc += TX) {
-      float s[8], q[8];
+      float s[8], q[8], piv[8];
+      int cnt = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-      for (int r = r_begin + ty; r < r_end; r += TY) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(xb + (size_t)r * C + cc * 8);
-        float f[8];
-        unpack8<DT>(v, f);
+      for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; piv[j] = 0.f; }
+      // four rows in flight per thread (latency-bound otherwise)
+      for (int r0 = r_begin + ty; r0 < r_end; r0 += 4 * TY) {
+        u32x4 v[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+        for (int u = 0; u < 4; ++u) {
+          const int r = min(r0 + u * TY, r_end - 1);
+          v[u] = *reinterpret_cast<const u32x4*>(xb + (size_t)r * C + cc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (r0 + u * TY >= r_end) break;
+          float f[8];
+          unpack8<DT>(v[u], f);
+          if (cnt == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piv[j] = f[j];          // shift = this thread's first value of the channel
+          }
+          ++cnt;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = f[j] - piv[j]; s[j] += d; q[j] = fmaf(d, d, q[j]); }
+        }
       }
+      const float n = (float)cnt, inv = cnt > 0 ? 1.0f / n : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s_sum[ty * C + cc * 8 + j] = s[j]; s_sq[ty * C + cc * 8 + j] = q[j]; }
+      for (int j = 0; j < 8; ++j) {
+        const float ms = s[j] * inv;                             // mean of the shifted values (small)
+        s_n[ty * C + cc * 8 + j] = n;
+        s_mean[ty * C + cc * 8 + j] = piv[j] + ms;
+        s_m2[ty * C + cc * 8 + j] = fmaxf(q[j] - s[j] * ms, 0.f);
+      }
     }
   }
   __syncthreads();
   if (tid < GN_GROUPS) {
     const int cpg = C / GN_GROUPS;
-    float a = 0.f, bq = 0.f;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int y = 0; y < TY; ++y)
-      for (int j = 0; j < cpg; ++j) { a += s_sum[y * C + tid * cpg + j]; bq += s_sq[y * C + tid * cpg + j]; }
+      for (int j = 0; j < cpg; ++j) {
+        const int i = y * C + tid * cpg + j;
+        chan_merge(n, mean, m2, s_n[i], s_mean[i], s_m2[i]);
+      }
     float* o = partial + (((size_t)b * nchunks + chunk) * GN_GROUPS + tid) * 2;
-    o[0] = a; o[1] = bq;
+    o[0] = mean; o[1] = m2;
   }
 }
 
@@ -76,17 +115,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / GN_GROUPS;
   if (tid < GN_GROUPS) {
-    double a = 0.0, q = 0.0;
+    // merge the chunk partials (mean_k, M2_k; count_k = rows of chunk k x cpg) with Chan's formula, fp64, fixed order
+    const int rows_per_c = (HW + nchunks - 1) / nchunks;
+    double n = 0.0, mu = 0.0, m2 = 0.0;
     for (int k = 0; k < nchunks; ++k) {
       const float* pp = partial + (((size_t)b * nchunks + k) * GN_GROUPS + tid) * 2;
-      a += (double)pp[0]; q += (double)pp[1];
+      const int rows_k = min(HW, (k + 1) * rows_per_c) - min(HW, k * rows_per_c);
+      const double nk = (double)rows_k * (double)cpg;
+      if (nk <= 0.0) continue;
+      const double nt = n + nk, d = (double)pp[0] - mu;
+      mu += d * nk / nt;
+      m2 += (double)pp[1] + d * d * n * nk / nt;
+      n = nt;
     }
-    const double n = (double)HW * (double)cpg;
-    const double mu = a / n;
-    double var = q / n - mu * mu;
-    if (var < 0.0) var = 0.0;
     mean[tid] = (float)mu;
-    rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    rstd[tid] = (float)(1.0 / sqrt(m2 / n + (double)eps));
   }
   __syncthreads();
   for (int ch = tid; ch < C; ch += 256) {
@@ -113,17 +156,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
     float scr[8], shr[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { scr[j] = sc[cc * 8 + j]; shr[j] = sh[cc * 8 + j]; }
-    for (int r = r_begin + ty; r < r_end; r += TY) {
-      const size_t off = (size_t)r * C + cc * 8;
-      u32x4 v = *reinterpret_cast<const u32x4*>(xb + off);
-      float f[8];
-      unpack8<DT>(v, f);
+    // four rows in flight per thread (one 16-B load each before the first use): the kernel is latency-bound otherwise
+    for (int r0 = r_begin + ty; r0 < r_end; r0 += 4 * TY) {
+      u32x4 v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float y = fmaf(f[j], scr[j], shr[j]);
-        f[j] = silu ? silu_f(y) : y;
+      for (int u = 0; u < 4; ++u) {
+        const int r = min(r0 + u * TY, r_end - 1);
+        v[u] = *reinterpret_cast<const u32x4*>(xb + (size_t)r * C + cc * 8);
       }
-      *reinterpret_cast<u32x4*>(ob + off) = pack8<DT>(f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * TY;
+        if (r >= r_end) break;
+        float f[8];
+        unpack8<DT>(v[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float y = fmaf(f[j], scr[j], shr[j]);
+          f[j] = silu ? silu_f(y) : y;
+        }
+        *reinterpret_cast<u32x4*>(ob + (size_t)r * C + cc * 8) = pack8<DT>(f);
+      }
     }
   }
 }
@@ -207,7 +260,7 @@ extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const
   hipStream_t s = (hipStream_t)stream;
   const int nchunks = gn_nchunks(HW);
   const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
-  const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
+  const size_t sm1 = (size_t)3 * TY * C * sizeof(float);
   const size_t sm2 = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(float);
   if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
   int nblk = (HW + TY * 8 - 1) / (TY * 8);                       // >= 8 rows per thread-row, <= 256 blocks per batch

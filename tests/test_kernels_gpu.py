@@ -248,6 +248,27 @@ def test_groupnorm(ops, ref, B, HW, C, silu):
     assert torch.equal(out, out2), "GroupNorm must be bitwise run-to-run deterministic"
 
 
+@pytest.mark.parametrize("B,HW,C", [(1, 4096, 320), (2, 1000, 640), (1, 144, 1920)])
+def test_groupnorm_large_mean_over_std(ops, B, HW, C):
+    """Variance is accumulated SHIFTED (per-thread pivot) and merged with Chan's formula, not as E[x^2] - mu^2: a group
+    whose |mean| is ~160x its std (about the most 8 mantissa bits can express) must still normalise to output rounding.
+    The inputs (256 + 2k, k in {-1, 0, 1}) are exact in bf16 and fp16, so the fp64 reference sees the kernel's values."""
+    g = torch.Generator().manual_seed(59)
+    k = torch.randint(-1, 2, (B, HW, C), generator=g).float()
+    x = 256.0 + 2.0 * k                                         # std 1.63, mean 256: E[x^2] - mu^2 in fp32 loses ~5 digits
+    assert torch.equal(to16(x).float(), x)
+    gm, bt = torch.ones(C), torch.zeros(C)
+    xd = x.double().view(B, HW, 32, C // 32)
+    mu = xd.mean(dim=(1, 3), keepdim=True)
+    var = xd.var(dim=(1, 3), unbiased=False, keepdim=True)
+    want = ((xd - mu) / (var + 1e-5).sqrt()).view(B, HW, C).float()
+    out = ops.groupnorm(dev(to16(x)), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, False)
+    torch.cuda.synchronize()
+    err = float((out.float().cpu() - want).abs().max())
+    print(f"[parity] groupnorm mean/std=157 B{B} HW{HW} C{C}: max abs err {err:.3e} (values up to {float(want.abs().max()):.2f})")
+    assert err < 6e-3                                           # one bf16 rounding of outputs up to ~1.23 is 3.9e-3
+
+
 @pytest.mark.parametrize("M,C", [(4096, 320), (1000, 640), (77, 1280), (5, 64), (184, 128)])
 def test_layernorm(ops, ref, M, C):
     x = to16(gen((M, C), 53) * 2 + 0.3)
@@ -353,7 +374,7 @@ def test_convnext_pieces(ops, ref):
 # ---------------------------------------------------------------------------------------------------
 # persistent big-tile GEMM / conv kernel (gemm_big.hip), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 1], ids=["1x8waves-256rows", "2x4waves-128rows"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["1x8waves-256rows", "2x4waves-128rows", "pingpong-256rows", "1x8waves-skewed-fill"])
 def big(request):
     """Force the persistent big-tile kernel (in both geometries) for every qualifying shape; yields a callable returning
     how many launches it served since the fixture started (so a test cannot pass on the 128x128 kernels by accident)."""
@@ -470,6 +491,46 @@ def test_conv3x3_big(ops, ref, big, B, H, W, Cin, Cout, stride, up):
     torch.cuda.synchronize()
     assert big() == 1
     assert relmax(out, want) < BF16_TOL
+
+
+def test_big_kernel_split_k(ops, ref):
+    """Few tiles, long K (the 8x8-level convs and ff-out GEMMs at batch 64: 64 tiles on 256 CUs): the persistent kernel
+    splits K over 4 work items per tile, fp32 partials in the workspace, epilogue in the reducer.  Default tuning (auto)."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import pack_conv3x3
+    lib = _lib.load()
+    start = lib.idf_get_stat(0)
+    # conv 8x8, batch 64, 1280 -> 1280 (K = 11520 = 180 K-tiles -> 4 slices of 45 on 64 tiles) with every epilogue term
+    B, H, W, Cin, Cout = 64, 8, 8, 1280, 1280
+    x = to16(gen((B, H, W, Cin), 60))
+    w4 = gen((Cout, Cin, 3, 3), 61, (9 * Cin) ** -0.5)
+    b = gen((Cout,), 62)
+    wp = to16(pack_conv3x3(w4))
+    rowb, res = to16(gen((B, Cout), 63)), to16(gen((B, H, W, Cout), 64))
+    want = ref.conv3x3(x.float(), wp.float(), torch.empty(B, H, W, Cout), bias=b, rowbias=rowb.float(), res=res.float())
+    out = ops.conv3x3(dev(x), dev(wp), ops.empty((B, H, W, Cout)), bias=dev(b), rowbias=dev(rowb), res=dev(res))
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 1, "the 8x8-level conv must run on the persistent kernel (split-K)"
+    assert relmax(out, want) < BF16_TOL
+    # dense ff-out GEMM at the 8x8 level: M = 4096, N = 1280, K = 5120 (80 K-tiles -> 4 slices of 20), in-place residual
+    M, N, K = 4096, 1280, 5120
+    a, w, bias = to16(gen((M, K), 65)), to16(gen((N, K), 66, K ** -0.5)), gen((N,), 67)
+    buf = dev(to16(gen((M, N), 68)))
+    want = buf.float().cpu() + a.float() @ w.float().t() + bias
+    ops.gemm(dev(a), dev(w), buf, bias=dev(bias), res=buf)
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 2
+    assert relmax(buf, want) < BF16_TOL
+    # exact data: split-K partial sums are exact in fp32 -> bitwise equal to the unsplit small-tile kernel
+    g = torch.Generator().manual_seed(69)
+    ai = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+    wi = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+    o1 = ops.gemm(dev(ai), dev(wi), ops.empty((M, N)))
+    lib.idf_set_tuning(0, 0)
+    o2 = ops.gemm(dev(ai), dev(wi), ops.empty((M, N)))
+    torch.cuda.synchronize()
+    lib.idf_set_tuning(0, 1)
+    assert torch.equal(o1, o2)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -44,14 +44,15 @@ def rec(name, sec, flops=None, bytes_=None):
 
 
 B = int(os.environ.get("DIAG_B", "2"))
-for (M, N, K, tag) in [(B * 4096, 320, 320, "proj 64^2"), (B * 4096, 640, 320, "qk 64^2"), (B * 4096, 2560, 320, "geglu-in 64^2"),
+SECTIONS = os.environ.get("DIAG_SECTIONS", "gemm,conv,attn,norm").split(",")
+for (M, N, K, tag) in [] if "gemm" not in SECTIONS else [(B * 4096, 320, 320, "proj 64^2"), (B * 4096, 640, 320, "qk 64^2"), (B * 4096, 2560, 320, "geglu-in 64^2"),
                        (B * 4096, 320, 1280, "ff-out 64^2"), (B * 1024, 640, 640, "proj 32^2"), (B * 1024, 5120, 640, "geglu-in 32^2"),
                        (B * 256, 1280, 1280, "proj 16^2"), (B * 256, 10240, 1280, "geglu-in 16^2"), (8192, 8192, 8192, "square 8k")]:
     a, w, o = rnd(M, K), rnd(N, K), ops.empty((M, N))
     rec(f"gemm {tag} M{M} N{N} K{K}", timeit(lambda: ops.gemm(a, w, o)), flops=2.0 * M * N * K)
 
 # epilogue cost on the short-K layers: same GEMM with bias+residual, and the packed GEGLU
-if os.environ.get("DIAG_EPI", "1") == "1":
+if os.environ.get("DIAG_EPI", "1") == "1" and "gemm" in SECTIONS:
     for (M, N, K, tag) in [(B * 4096, 320, 320, "proj 64^2"), (B * 1024, 640, 640, "proj 32^2")]:
         a, w, o = rnd(M, K), rnd(N, K), ops.empty((M, N))
         bias, resid = torch.randn(N, device="cuda"), rnd(M, N)
@@ -61,12 +62,12 @@ if os.environ.get("DIAG_EPI", "1") == "1":
         bias = torch.randn(8 * C, device="cuda")
         rec(f"gemm+geglu {tag} M{M} N{8 * C} K{C}", timeit(lambda: ops.gemm(a, w, o, bias=bias, geglu=True)), flops=2.0 * M * 8 * C * C)
 
-for (H, Cin, Cout, tag) in [(64, 320, 320, "64^2 320"), (32, 640, 640, "32^2 640"), (16, 1280, 1280, "16^2 1280"),
+for (H, Cin, Cout, tag) in [] if "conv" not in SECTIONS else [(64, 320, 320, "64^2 320"), (32, 640, 640, "32^2 640"), (16, 1280, 1280, "16^2 1280"),
                             (8, 2560, 1280, "8^2 2560->1280"), (64, 960, 320, "64^2 960->320"), (32, 1920, 640, "32^2 1920->640")]:
     x, w, o = rnd(B, H, H, Cin), rnd(Cout, 9 * Cin), ops.empty((B, H, H, Cout))
     rec(f"conv3x3 {tag} B{B}", timeit(lambda: ops.conv3x3(x, w, o)), flops=2.0 * B * H * H * Cout * 9 * Cin)
 
-for (N, d, n1, tag) in [(4096, 40, 0, "self 64^2"), (4096, 40, 184, "gated 64^2"), (1024, 80, 184, "gated 32^2"),
+for (N, d, n1, tag) in [] if "attn" not in SECTIONS else [(4096, 40, 0, "self 64^2"), (4096, 40, 184, "gated 64^2"), (1024, 80, 184, "gated 32^2"),
                         (256, 160, 184, "gated 16^2"), (4096, 40, -77, "cross 64^2")]:
     C = 8 * d
     q = rnd(B, N, C)
@@ -83,15 +84,16 @@ for (N, d, n1, tag) in [(4096, 40, 0, "self 64^2"), (4096, 40, 184, "gated 64^2"
         kw = dict(k1=rnd(B, 184, C), vt1=rnd(B, C, 192), n1=184)
     rec(f"attn {tag} B{B} d{d}", timeit(lambda: ops.attention(q, k0, vt0, n0, o, 8, **kw)), flops=4.0 * B * N * (n0 + n1) * C)
 
-for (HW, C) in [(4096, 320), (4096, 960), (1024, 1920), (64, 2560)]:
+NORM = "norm" in SECTIONS
+for (HW, C) in [(4096, 320), (4096, 960), (1024, 1920), (64, 2560)] if NORM else []:
     x, o = rnd(B, HW, C), ops.empty((B, HW, C))
     gm, bt = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     rec(f"groupnorm+silu HW{HW} C{C} B{B}", timeit(lambda: ops.groupnorm(x, o, gm, bt, 1e-5, True)), bytes_=4.0 * B * HW * C)
-for (M, C) in [(B * 4096, 320), (B * 1024, 640), (B * 256, 1280)]:
+for (M, C) in [(B * 4096, 320), (B * 1024, 640), (B * 256, 1280)] if NORM else []:
     x, o = rnd(M, C), ops.empty((M, C))
     gm, bt = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     rec(f"layernorm M{M} C{C}", timeit(lambda: ops.layernorm(x, o, gm, bt)), bytes_=4.0 * M * C)
-for (H, Ch, Cs) in [(64, 320, 320), (32, 640, 640), (8, 1280, 1280)]:
+for (H, Ch, Cs) in [(64, 320, 320), (32, 640, 640), (8, 1280, 1280)] if NORM else []:
     h, s, o = rnd(B, H, H, Ch), rnd(B, H, H, Cs), ops.empty((B, H, H, Ch + Cs))
     hs, sm1 = torch.ones(Ch, device="cuda"), torch.full((1,), 0.2, device="cuda")
     rec(f"scaleu H{H} {Ch}+{Cs} B{B}", timeit(lambda: ops.scaleu_concat(h, s, o, hs, sm1)), bytes_=4.0 * B * H * H * (Ch + Cs))

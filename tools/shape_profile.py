@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 class ShapeTimer(bench.OpTimer):
     def __getattr__(self, name):
         fn = getattr(self.ops, name)
-        if name not in ("gemm", "conv3x3", "attention", "groupnorm", "layernorm", "scaleu_concat"):
+        if name not in ("gemm", "conv3x3", "attention", "groupnorm", "layernorm", "scaleu_concat", "row_stats"):
             return fn
 
         def timed(*a, **k):

@@ -38,6 +38,19 @@ template <int I, int N, int STEP, class F> __device__ __forceinline__ void stati
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA as inline assembly: with the builtin the compiler orders every later ds_read behind ALL outstanding LDS-DMA
+// (s_waitcnt vmcnt(0)); both kernels below keep LDS-DMA in flight across their fragment reads and do their own waits.  lds = LDS byte address of lane 0's 16-B slot (lane i lands at lds + 16 i); it goes through M0, which
+// nothing else in that kernel uses.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ void dma16_sv(const void* sbase /* wave-uniform */, unsigned voff_bytes, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(addr) : "memory");
+}
+
 // ---------------- tile epilogue (shared by the lock-step and the ping-pong kernel): no LDS, no barrier.
 // acc[a][b][4q+e] = D[n = a*32 + 8q + 4hi + e][m = b*32 + l31].  Two v_permlane32_swap per register pair
 // (q0 <-> q2, q1 <-> q3 between the lane halves) leave every lane with 16 CONSECUTIVE columns of its row:
@@ -267,46 +280,52 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
     if (CONV) { const int k_elem = l_k0 * BKT; tap = k_elem / p.Cin; ci0 = k_elem - tap * p.Cin; }
   };
 
-  auto issue_dma = [&](int stage) {                       // enqueue K-tile l_kt of tile l_seq into `stage`, then advance
+  // LDS-DMA pieces of the K-tile the loader stands on: piece i < W_INST = weight rows, else activation rows.  Inline
+  // assembly (dma16_*): the fill of the NEXT stage is spread between the MFMAs and fragment reads of this one, and with the
+  // builtin the compiler would order every later ds_read behind it (s_waitcnt vmcnt(0)) or sink the piece past the MFMAs.
+  auto issue_piece = [&](int stage, auto II) {
+    constexpr int i = decltype(II)::value;
     unsigned short* Al = smem + stage * STAGE;
-    unsigned short* Wl = Al + BM * RS;
-    const unsigned short* Wk = p.W + (size_t)(l_k0 + l_kt) * BKT;
-#pragma unroll
-    for (int j = 0; j < W_INST; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wk + woff[j]), (lptr_t)(Wl + RPI * (wave + NW * j) * RS), 16, 0, 0);
-    if (CONV) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
-      const unsigned short* Ak = p.A + ci0;
-#pragma unroll
-      for (int j = 0; j < A_INST; ++j) {
+    if constexpr (i < W_INST) {
+      constexpr int j = i;
+      dma16_sv(p.W + (size_t)(l_k0 + l_kt) * BKT, woff[j] * 2u, lds_addr(Al + BM * RS + RPI * (wave + NW * j) * RS));
+    } else {
+      constexpr int j = i - W_INST;
+      const unsigned dst = lds_addr(Al + RPI * (wave + NW * j) * RS);
+      if (CONV) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
         const int yi = (ayx[j] >> 16) + ky, xi = (int)(short)(ayx[j] & 0xffff) + kx;
         const bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
         const int ys = yi >> p.up, xs = xi >> p.up;
-        const unsigned short* src = ok ? Ak + (aoff[j] + (unsigned)(ys * p.Win + xs) * (unsigned)p.lda)
-                                       : idf_zero_page + dc * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Al + RPI * (wave + NW * j) * RS), 16, 0, 0);
+        const unsigned short* src = ok ? p.A + ci0 + (aoff[j] + (unsigned)(ys * p.Win + xs) * (unsigned)p.lda) : idf_zero_page + dc * 8;
+        dma16_v(src, dst);
+      } else {
+        dma16_sv(p.A + (size_t)(l_k0 + l_kt) * BKT, aoff[j] * 2u, dst);
       }
-      ci0 += BKT;
-      if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
-    } else {
-      const unsigned short* Ak = p.A + (size_t)(l_k0 + l_kt) * BKT;
-#pragma unroll
-      for (int j = 0; j < A_INST; ++j)
-        __builtin_amdgcn_global_load_lds((gptr_t)(Ak + aoff[j]), (lptr_t)(Al + RPI * (wave + NW * j) * RS), 16, 0, 0);
     }
+  };
+  auto advance_loader = [&]() {
+    if (CONV) { ci0 += BKT; if (ci0 >= p.Cin) { ci0 = 0; ++tap; } }
     if (++l_kt == nk) {
       l_kt = 0;
       l_seq += G;
       if (l_seq < tiles_total) setup_loader(l_seq);
     }
   };
+  auto issue_dma = [&](int stage) {                       // enqueue the whole K-tile into `stage`, then advance
+    static_for<0, DPW, 1>([&](auto II) { issue_piece(stage, II); });
+    advance_loader();
+  };
 
   // ---------------- MFMA side
   f32x16 acc[TN][TM];
   const int f_sw = swz(l31);                              // fragment rows are (multiple of 32) + l31
   int issued = 0;                                         // K-tiles enqueued so far
-  auto compute = [&](int stage, bool late_fill, int st_fill) {
+  constexpr int NPOS = (BKT / 16) * TN;                   // (k-step, weight fragment) positions of a K-tile: TM MFMAs each
+  // fill modes (`skew`, see the K loop): 0 burst before the MFMAs; 1 / 2: the second half of the workgroup bursts after the
+  // middle / last position; 3: one piece every second position, the two halves on alternating positions
+  auto compute = [&](int stage, int mode, int par, int st_fill) {
     const unsigned short* Al = smem + stage * STAGE;
     const unsigned short* Wl = Al + BM * RS;
     const unsigned short* af_base = Al + (wm * WM + l31) * RS;
@@ -319,25 +338,34 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
 #pragma unroll
       for (int b = 0; b < TM; ++b) af[0][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + s8);
     }
-#pragma unroll
-    for (int ks = 0; ks < BKT / 16; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < BKT / 16) {
+    static_for<0, BKT / 16, 1>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      constexpr int cur = ks & 1, nxt = cur ^ 1;
+      if constexpr (ks + 1 < BKT / 16) {
         const int s8 = (((ks + 1) * 2 + hi) ^ f_sw) * 8;
 #pragma unroll
         for (int a = 0; a < TN; ++a) wf[nxt][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + s8);
 #pragma unroll
         for (int b = 0; b < TM; ++b) af[nxt][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + s8);
       }
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
+      static_for<0, TN, 1>([&](auto AI) {
+        constexpr int a = decltype(AI)::value;
+        constexpr int pos = ks * TN + a;
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
-      if (ks == BKT / 32 - 1 && late_fill) {              // skewed half of the workgroup: refill from the middle of the K-tile
-        issue_dma(st_fill);
-        ++issued;
-      }
+        if constexpr (pos / 2 < DPW) {
+          if (mode == 3 && ((pos & 1) ^ par)) issue_piece(st_fill, IC<pos / 2>{});
+        }
+        if constexpr (pos == NPOS / 2 - 1) {
+          if (mode == 1 && par) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
+        }
+      });
+    });
+    if (mode == 2 && par) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
+    if constexpr (2 * DPW > NPOS) {                       // spread mode, short K-tiles: the pieces that found no position
+      if (mode == 3) static_for<NPOS / 2, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
     }
+    if (mode > 0) { advance_loader(); ++issued; }
   };
 
   int seq = slot;
@@ -369,18 +397,23 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
       __builtin_amdgcn_s_barrier();                       // ... and every wave has finished reading the stage refilled below
       asm volatile("" ::: "memory");
       // An LDS-DMA instruction holds the issuing wave for ~180-240 cycles (tools/ubench/dma_rate.hip: 5.6 B/clk per wave,
-      // 34 B/clk per CU), during which it issues no MFMA.  With `skew` the second half of the workgroup (the partner wave on
-      // every SIMD) enqueues its pieces from the MIDDLE of its K-tile, so that one wave of a SIMD feeds the matrix pipe
-      // while the other is held in the memory pipe.
+      // 34 B/clk per CU), during which it issues no MFMA.  `skew` de-phases the two waves of a SIMD so that one feeds the
+      // matrix pipe while the other is held in the memory pipe: 1 / 2 = the second half of the workgroup enqueues its pieces
+      // from the middle / the end of its K-tile, 3 = every wave spreads its pieces between its MFMAs, the halves alternating.
       const bool fill = l_seq < tiles_total;
       int st_fill = st_it + NSTG - 1;
       if (st_fill >= NSTG) st_fill -= NSTG;
-      const bool late = fill && skew && wave >= NW / 2;
-      if (fill && !late) {
-        issue_dma(st_fill);
-        ++issued;
+      int mode = 0;
+      const int par = wave >= NW / 2 ? 1 : 0;
+      if (fill) {
+        if (skew == 3) mode = 3;
+        else if (skew && par) mode = skew;
+        if (mode == 0) {
+          issue_dma(st_fill);
+          ++issued;
+        }
       }
-      compute(st_it, late, st_fill);
+      compute(st_it, mode, par, st_fill);
       ++it;
       if (++st_it == NSTG) st_it = 0;
     }
@@ -389,20 +422,6 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
     // wave of its SIMD is still in the K-loop
     big_epilogue<DT, BM, BN, TN, SPLIT>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate);
   }
-}
-
-// LDS-DMA as inline assembly: with the builtin the compiler orders every later ds_read behind ALL outstanding LDS-DMA
-// (s_waitcnt vmcnt(0)); the ping-pong kernel keeps three half-tiles in flight across its fragment reads and does its own
-// counted waits.  lds = LDS byte address of lane 0's 16-B slot (lane i lands at lds + 16 i); it goes through M0, which
-// nothing else in that kernel uses.
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
-__device__ __forceinline__ void dma16_sv(const void* sbase /* wave-uniform */, unsigned voff_bytes, unsigned lds) {
-  lds = __builtin_amdgcn_readfirstlane(lds);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_bytes), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigned lds) {
-  lds = __builtin_amdgcn_readfirstlane(lds);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(addr) : "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -682,9 +701,12 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   const int tiles = (p.N / BN) * ((p.M + BM - 1) / BM) * splitk;   // work items
   const int slots = num_cu() * (BM == 128 ? 2 : 1);
   const int grid = tiles < slots ? tiles : slots;
-  // skewed fill: geometry 3 always, geometry 0 on K >= 640 (measured +1.5..3.5 % there, -1..2 % on the K = 320 layers)
+  // fill schedule (kernel comment): geometry 3 / 4 / 5 force skew 2 / 1 / 3; geometry 0 = the measured default per K
   const int geom = idf_big_geom();
-  const int skew = (geom == 3 || (geom == 0 && p.K >= 640)) ? 1 : 0;
+  int skew = 0;
+  if (geom == 3) skew = 2;
+  else if (geom == 5) skew = 3;
+  else if (geom == 0 || geom == 4 || geom == 6) skew = 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BM * 2), smem, s, q, tiles, skew);
   return idf_launch_status();
 }
@@ -781,6 +803,10 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if (geom == 1) {                                                                                                        \
     if (conv) return bn == 320 ? launch_big_cfg<DT, 128, 320, 32, 2, true>(p, s) : launch_big_cfg<DT, 128, 256, 32, 3, true>(p, s);   \
     return bn == 320 ? launch_big_cfg<DT, 128, 320, 32, 2, false>(p, s) : launch_big_cfg<DT, 128, 256, 32, 3, false>(p, s);           \
+  }                                                                                                                       \
+  if (geom == 6 && bn == 256 && splitk == 1) {                                                                            \
+    if (conv) return launch_big_cfg<DT, 256, 256, 32, 4, true>(p, s);                                                     \
+    return launch_big_cfg<DT, 256, 256, 32, 4, false>(p, s);                                                              \
   }                                                                                                                       \
   if (conv) return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, true>(p, s, splitk) : launch_big_cfg<DT, 256, 256, 64, 2, true>(p, s, splitk);     \
   return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, false>(p, s, splitk) : launch_big_cfg<DT, 256, 256, 64, 2, false>(p, s, splitk);

@@ -614,7 +614,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
     return prev;
   }
   if (knob == IDF_TUNE_GEMM_GEOM) {
-    if (value < 0 || value > 3) return IDF_E_ARG;
+    if (value < 0 || value > 6) return IDF_E_ARG;
     return idf_big_set_geom(value);
   }
   if (knob == IDF_TUNE_ATTN2) {

@@ -8,6 +8,7 @@
 // Algorithmic bytes: 2 B read + 2 B written per element (the 2nd read of x is served by L2 / Infinity Cache for the
 // <= 100 MB activations of this UNet).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -33,10 +34,10 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 }
 
 // partial[b][chunk][g][2] = (mean, M2) over the rows of the chunk (count = rows in the chunk x channels per group)
-template <int DT>
+template <int DT, int UNR>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ partial,
                                                       int HW, int C, int nchunks) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];     // [3][TY][C]: count, mean, M2 per (row lane, channel)
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [2][TY][C]: mean, M2 per (row lane, channel)
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cpr = C >> 3;                                        // 16-B chunks per row
   const int TX = cpr < 256 ? cpr : 256;
@@ -47,9 +48,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __r
   const int r_begin = chunk * rows_per;
   const int r_end = min(HW, r_begin + rows_per);
   const unsigned short* xb = x + (size_t)b * HW * C;
-  float* s_n = sm;
-  float* s_mean = sm + (size_t)TY * C;
-  float* s_m2 = sm + 2 * (size_t)TY * C;
+  float* s_mean = sm;
+  float* s_m2 = sm + (size_t)TY * C;
   if (ty < TY) {
     for (int cc = tx; cc < cpr; cc += TX) {
       float s[8], q[8], piv[8];
@@ -57,15 +57,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __r
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; piv[j] = 0.f; }
       // four rows in flight per thread (latency-bound otherwise)
-      for (int r0 = r_begin + ty; r0 < r_end; r0 += 4 * TY) {
-        u32x4 v[4];
+      for (int r0 = r_begin + ty; r0 < r_end; r0 += UNR * TY) {
+        u32x4 v[UNR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
           const int r = min(r0 + u * TY, r_end - 1);
           v[u] = *reinterpret_cast<const u32x4*>(xb + (size_t)r * C + cc * 8);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
           if (r0 + u * TY >= r_end) break;
           float f[8];
           unpack8<DT>(v[u], f);
@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __r
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float ms = s[j] * inv;                             // mean of the shifted values (small)
-        s_n[ty * C + cc * 8 + j] = n;
         s_mean[ty * C + cc * 8 + j] = piv[j] + ms;
         s_m2[ty * C + cc * 8 + j] = fmaxf(q[j] - s[j] * ms, 0.f);
       }
@@ -92,17 +91,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __r
   if (tid < GN_GROUPS) {
     const int cpg = C / GN_GROUPS;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int y = 0; y < TY; ++y)
-      for (int j = 0; j < cpg; ++j) {
-        const int i = y * C + tid * cpg + j;
-        chan_merge(n, mean, m2, s_n[i], s_mean[i], s_m2[i]);
-      }
+    const float inv_cpg = 1.0f / (float)cpg;
+    for (int y = 0; y < TY; ++y) {
+      // the cpg channel summaries of one row lane have EQUAL counts: merged without divisions (mean of means,
+      // M2 = sum M2_j + n_y * sum (mean_j - mean)^2), then one general Chan merge per row lane
+      const int i0 = y * C + tid * cpg;
+      const int rows_y = (r_end - r_begin - y + TY - 1) / TY;        // rows r_begin + y, + TY, ... of this chunk
+      if (rows_y <= 0) continue;
+      const float ny = (float)rows_y;
+      float ms = 0.f, q = 0.f;
+      for (int j = 0; j < cpg; ++j) { ms += s_mean[i0 + j]; q += s_m2[i0 + j]; }
+      const float my = ms * inv_cpg;
+      float dev = 0.f;
+      for (int j = 0; j < cpg; ++j) { const float d = s_mean[i0 + j] - my; dev = fmaf(d, d, dev); }
+      chan_merge(n, mean, m2, ny * (float)cpg, my, fmaf(ny, dev, q));
+    }
     float* o = partial + (((size_t)b * nchunks + chunk) * GN_GROUPS + tid) * 2;
     o[0] = mean; o[1] = m2;
   }
 }
 
-template <int DT>
+template <int DT, int UNR>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ partial, int HW, int C, int nchunks,
@@ -157,15 +166,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) { scr[j] = sc[cc * 8 + j]; shr[j] = sh[cc * 8 + j]; }
     // four rows in flight per thread (one 16-B load each before the first use): the kernel is latency-bound otherwise
-    for (int r0 = r_begin + ty; r0 < r_end; r0 += 4 * TY) {
-      u32x4 v[4];
+    for (int r0 = r_begin + ty; r0 < r_end; r0 += UNR * TY) {
+      u32x4 v[UNR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         const int r = min(r0 + u * TY, r_end - 1);
         v[u] = *reinterpret_cast<const u32x4*>(xb + (size_t)r * C + cc * 8);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         const int r = r0 + u * TY;
         if (r >= r_end) break;
         float f[8];
@@ -260,24 +269,27 @@ extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const
   hipStream_t s = (hipStream_t)stream;
   const int nchunks = gn_nchunks(HW);
   const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
-  const size_t sm1 = (size_t)3 * TY * C * sizeof(float);
+  const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
   const size_t sm2 = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(float);
   if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
   int nblk = (HW + TY * 8 - 1) / (TY * 8);                       // >= 8 rows per thread-row, <= 256 blocks per batch
   if (nblk < 1) nblk = 1;
   if (nblk > 256) nblk = 256;
   dim3 g1(nchunks, B), g2(nblk, B);
+  static int unr = -1;                                          // rows in flight per thread (IDF_GN_UNROLL=1|4 for A/B runs)
+  if (unr < 0) { const char* e = getenv("IDF_GN_UNROLL"); unr = (e && atoi(e) == 1) ? 1 : 4; }
+#define IDF_GN_LAUNCH(DT, U)                                                                                              \
+  hipLaunchKernelGGL((gn_stats_kernel<DT, U>), g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);      \
+  hipLaunchKernelGGL((gn_apply_kernel<DT, U>), g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,     \
+                     gamma, beta, ws, HW, C, nchunks, eps, silu, nblk);
   if (dtype == IDF_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<IDF_BF16>, g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);
-    hipLaunchKernelGGL(gn_apply_kernel<IDF_BF16>, g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,
-                       gamma, beta, ws, HW, C, nchunks, eps, silu, nblk);
+    if (unr == 1) { IDF_GN_LAUNCH(IDF_BF16, 1) } else { IDF_GN_LAUNCH(IDF_BF16, 4) }
   } else if (dtype == IDF_F16) {
-    hipLaunchKernelGGL(gn_stats_kernel<IDF_F16>, g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);
-    hipLaunchKernelGGL(gn_apply_kernel<IDF_F16>, g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,
-                       gamma, beta, ws, HW, C, nchunks, eps, silu, nblk);
+    if (unr == 1) { IDF_GN_LAUNCH(IDF_F16, 1) } else { IDF_GN_LAUNCH(IDF_F16, 4) }
   } else {
     return IDF_E_UNSUPPORTED;
   }
+#undef IDF_GN_LAUNCH
   return idf_launch_status();
 }
 

@@ -374,7 +374,8 @@ def test_convnext_pieces(ops, ref):
 # ---------------------------------------------------------------------------------------------------
 # persistent big-tile GEMM / conv kernel (gemm_big.hip), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 1, 2, 3], ids=["1x8waves-256rows", "2x4waves-128rows", "pingpong-256rows", "1x8waves-skewed-fill"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["1x8waves-256rows", "2x4waves-128rows", "pingpong-256rows", "1x8waves-fill-end",
+                                             "1x8waves-fill-middle", "1x8waves-fill-spread"])
 def big(request):
     """Force the persistent big-tile kernel (in both geometries) for every qualifying shape; yields a callable returning
     how many launches it served since the fixture started (so a test cannot pass on the 128x128 kernels by accident)."""

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   CoreParams p{};
   p.W = w; p.ldw = K; p.N = N; p.A = a; p.lda = K; p.M = M; p.K = K; p.out = o; p.ldo = N; p.epi = 0; p.n_valid = N;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int geom : {0, 3, 2}) {
+  for (int geom : {0, 3, 5, 6, 2}) {
     if (geom == 2) printf("IDF_GEMM_PP_DL=%s\n", getenv("IDF_GEMM_PP_DL") ? getenv("IDF_GEMM_PP_DL") : "0");
     idf_big_set_geom(geom);
     int rc = idf_launch_big(p, IDF_BF16, false, true, 0, nullptr);

@@ -31,8 +31,12 @@ constexpr int VSTR = 72;           // V^T LDS row stride in elements (144 B = 9 
 #endif
 // MASK: instance-visibility bit masks (see AttnParams): the tile's 64 key words ride along in LDS; a score whose
 // (query word & key word) is zero -- and which is not the query's own token -- becomes -inf before the softmax.
-template <int DT, int NKS, int NMT, bool MFMASUM, bool MASK = false>
-__global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn_kernel(const AttnParams p) {
+// RES ("resident keys"): the whole key set fits the two LDS buffers (n0 + n1 tiles <= 2: cross-attention on the 77 text
+// tokens).  K / V^T are staged ONCE per workgroup, which then walks `qpw` blocks of 128 queries with the next block's Q
+// fragments prefetched -- the per-block staging, LDS clears and barriers made those launches latency-bound (190 us
+// against a 42 us HBM bound at 64x64).
+template <int DT, int NKS, int NMT, bool MFMASUM, bool MASK = false, bool RES = false>
+__global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn_kernel(const AttnParams p, const int qpw) {
   constexpr int KSTR = (2 * NKS + 1) * 8;          // K LDS row stride (elements): odd number of 16-B slots
   constexpr int KCH_MAX = (KVT * 2 * NKS + 255) / 256;
   constexpr int VCH_MAX = (NMT * 32 * 8 + 255) / 256;
@@ -46,7 +50,9 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = p.d;
   const int dch = d >> 3;                            // 16-B chunks per K row
-  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+  const int nqb = (p.nq + 127) / 128;
+  const int qb0 = RES ? (int)blockIdx.x * qpw : (int)blockIdx.x;
+  const int qb1 = RES ? min(nqb, qb0 + qpw) : qb0 + 1;
 
   // zero LDS once: pad columns of K (d..16*NKS) and pad rows of V^T (d..32*NMT) must stay finite zeros
   for (int i = tid; i < KSZ; i += 256) reinterpret_cast<unsigned*>(Kl)[i] = 0u;
@@ -58,21 +64,19 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
   }
 
   // ---- Q fragments (B operand): lane holds q = l31, e = 16*ks + 8*hi .. +7
-  u32x4 qf[NKS];
-  {
-    const int qr = min(qrow, p.nq - 1);
+  auto load_q = [&](int qblk, u32x4* dst) {
+    const int qr = min(qblk * 128 + wave * 32 + l31, p.nq - 1);
     const unsigned short* qp = p.q + (size_t)b * p.sQ + (size_t)qr * p.ldq + h * d;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int e0 = ks * 16 + hi * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (e0 < d) v = *reinterpret_cast<const u32x4*>(qp + e0);
-      qf[ks] = v;
+      dst[ks] = v;
     }
-  }
-
-  unsigned qb = 0xffffffffu;
-  if (MASK) qb = p.qbits[(size_t)b * p.sQb + min(qrow, p.nq - 1)];
+  };
+  u32x4 qf[NKS];
+  load_q(qb0, qf);
 
   const int T0 = (p.n[0] + KVT - 1) / KVT;
   const int T1 = (p.n[1] + KVT - 1) / KVT;
@@ -155,19 +159,26 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
       }
   };
 
-  f32x16 o[NMT];
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[mt][r] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f;
   const float c = p.scale_log2;
 
   prefetch(0);
   __syncthreads();              // zero-fill of both LDS buffers complete
   commit(0);
   if (T > 1) prefetch(1);
+  if (RES && T > 1) commit(1);  // resident keys: both tiles staged once, no staging inside the tile loop
   __syncthreads();
+  for (int qblk = qb0; qblk < qb1; ++qblk) {
+  const int qrow = qblk * 128 + wave * 32 + l31;
+  unsigned qb = 0xffffffffu;
+  if (MASK) qb = p.qbits[(size_t)b * p.sQb + min(qrow, p.nq - 1)];
+  u32x4 qnext[RES ? NKS : 1];
+  if (RES && qblk + 1 < qb1) load_q(qblk + 1, qnext);
+  f32x16 o[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[mt][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
   for (int t = 0; t < T; ++t) {
     // Invariant: buffer t&1 holds tile t (visible to all waves); registers hold tile t+1 (loads in flight).
     const unsigned short* Kc = Kl + (t & 1) * KSZ;
@@ -264,11 +275,13 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     }
     // stage the next tile into the OTHER buffer (last read in iteration t-1; every wave passed that barrier), then
     // fetch tile t+2 into the registers; one barrier per tile.
-    if (t + 1 < T) {
-      commit((t + 1) & 1);
-      if (t + 2 < T) prefetch(t + 2);
+    if (!RES) {
+      if (t + 1 < T) {
+        commit((t + 1) & 1);
+        if (t + 2 < T) prefetch(t + 2);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- normalise and store.  o[mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
@@ -297,20 +310,40 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
         }
       }
   }
+  if (RES) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = qnext[ks];
+  }
+  }   // query blocks
 }
 
 template <int DT>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
-  dim3 grid((p.nq + 127) / 128, p.H, B), block(256);
+  const int nqb = (p.nq + 127) / 128;
+  dim3 grid(nqb, p.H, B), block(256);
   const int nks = (p.d + 15) / 16, nmt = (p.d + 31) / 32;
+  // resident-key path: <= 2 key tiles in total, no mask; enough query blocks per workgroup to amortise the staging while
+  // the grid still covers the chip ~4x
+  const int tiles = (p.n[0] + KVT - 1) / KVT + (p.n[1] + KVT - 1) / KVT;
+  int qpw = 1;
+  const bool res = !p.qbits && tiles <= 2 && nqb >= 2;
+  if (res) {
+    const long long blocks = (long long)nqb * p.H * B;
+    qpw = (int)(blocks / 1024);
+    qpw = qpw < 1 ? 1 : (qpw > 8 ? 8 : qpw);
+  }
+  dim3 grid_res((nqb + qpw - 1) / qpw, p.H, B);
 #define IDF_ATTN_CASE(KS, MT) \
   if (nks == KS && nmt == MT) { \
     if (p.qbits) { \
-      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true, true>), grid, block, 0, s, p); \
-      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false, true>), grid, block, 0, s, p); \
+      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true, true>), grid, block, 0, s, p, 1); \
+      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false, true>), grid, block, 0, s, p, 1); \
+    } else if (res && qpw > 1) { \
+      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true, false, true>), grid_res, block, 0, s, p, qpw); \
+      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false, false, true>), grid_res, block, 0, s, p, qpw); \
     } else { \
-      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true>), grid, block, 0, s, p); \
-      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false>), grid, block, 0, s, p); \
+      if (p.d < 32 * MT) hipLaunchKernelGGL((attn_kernel<DT, KS, MT, true>), grid, block, 0, s, p, 1); \
+      else hipLaunchKernelGGL((attn_kernel<DT, KS, MT, false>), grid, block, 0, s, p, 1); \
     } \
     return idf_launch_status(); }
   IDF_ATTN_CASE(1, 1)    // d = 8, 16

@@ -203,6 +203,24 @@ def test_attention(ops, ref, B, H, d, Nq, n0, n1):
     assert relmax(out, want) < 2 * BF16_TOL          # P is rounded to bf16 inside the kernel
 
 
+@pytest.mark.parametrize("B,H,d,Nq,n0", [(8, 8, 40, 4096 + 40, 77), (32, 8, 80, 1024, 77), (8, 8, 160, 4096, 77),
+                                         (16, 8, 40, 2048, 128), (20, 8, 40, 1024, 40)])
+def test_attention_resident_keys(ops, ref, B, H, d, Nq, n0):
+    """Cross-attention shapes large enough for the resident-key path (<= 2 key tiles staged once per workgroup, which then
+    walks several 128-query blocks; launch_attn picks it from B * H * query blocks >= 2048): ragged last block, one- and
+    two-tile key sets, all three head dims of the UNet."""
+    C = H * d
+    q, k0, v0 = to16(gen((B, Nq, C), 70)), to16(gen((B, n0, C), 71)), to16(gen((B, n0, C), 72))
+    ld0 = (n0 + 63) // 64 * 64
+    vt0 = torch.full((B, C, ld0), float("nan"), dtype=torch.bfloat16)        # pad must be masked by the kernel
+    vt0[:, :, :n0] = v0.transpose(1, 2)
+    want = ref.attention(q.float(), k0.float(), torch.nan_to_num(vt0.float()), n0, torch.empty(B, Nq, C), H)
+    out = ops.attention(dev(q), dev(k0), dev(vt0), n0, ops.empty((B, Nq, C)), H)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert relmax(out, want) < 2 * BF16_TOL
+
+
 def test_attention_forced_rescale(ops, ref):
     """Online-softmax rescale branch: a spiked key in a LATE tile must rescale earlier accumulations."""
     B, H, d, N = 1, 8, 40, 512

@@ -24,13 +24,34 @@ def load(d, counter):
     return tot, n
 
 
+def _targs(name):
+    """Template arguments of a demangled kernel name, e.g. 'gemm_kernel_big<0, 256, 320, 64, 2, true, false>(...)'."""
+    if "<" not in name:
+        return []
+    inner = name[name.index("<") + 1:name.rindex(">")] if ">" in name else ""
+    return [a.strip() for a in inner.split(",")]
+
+
 def family(name):
     if "attn" in name:
         return "attention"
-    if "gemm_kernel" in name or "splitk_reduce" in name:
-        if "true>" in name.replace(" ", "") or "Lb1" in name:
-            return "conv3x3"
-        return "gemm"
+    if "splitk_reduce" in name:
+        return "conv3x3"                         # only the 8x8-level convs / ff-out GEMMs split K; booked with the convs
+    if "gemm_kernel_big" in name:                # <DT, BM, BN, BKT, NSTG, CONV, SPLIT>
+        a = _targs(name)
+        return "conv3x3" if len(a) > 5 and a[5] in ("true", "1") else "gemm"
+    if "gemm_kernel_pp" in name:                 # <DT, BN, CONV, DL>
+        a = _targs(name)
+        return "conv3x3" if len(a) > 2 and a[2] in ("true", "1") else "gemm"
+    if "gemm_kernel" in name:                    # <DT, BM, BN, WM, WN, CONV>
+        a = _targs(name)
+        return "conv3x3" if a and a[-1] in ("true", "1") else "gemm"
+    if "row_stats" in name:
+        return "gemm"                            # the LayerNorm statistics pass belongs to the GEMM that consumes it
+    if "gn_stats" in name or "gn_apply" in name:
+        return "groupnorm"
+    if "scaleu" in name:
+        return "scaleu_concat"
     return None
 
 

@@ -119,28 +119,49 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
   extern __shared__ __attribute__((aligned(16))) float sm[];     // scale[C], shift[C], mean[32], rstd[32]
   float* sc = sm;
   float* sh = sm + C;
-  float* mean = sm + 2 * C;
+  float* mean = sm + (2 * C > 512 ? 2 * C : 512);                // the first 2 KB double as the fp64 reduction scratch
   float* rstd = mean + GN_GROUPS;
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / GN_GROUPS;
-  if (tid < GN_GROUPS) {
-    // merge the chunk partials (mean_k, M2_k; count_k = rows of chunk k x cpg) with Chan's formula, fp64, fixed order
+  // Merge the chunk partials (mean_k, M2_k; count n_k = rows of chunk k x cpg): mean = sum n_k mean_k / N,
+  // M2 = sum M2_k + sum n_k (mean_k - mean)^2 -- the pairwise (Chan) update written as two weighted sums, so that the 256
+  // threads share the work (8 chunk slices x 32 groups, fp64, fixed order -> bitwise reproducible) and no thread runs a
+  // chain of 64 fp64 divisions in front of every row block.
+  {
+    double* red = reinterpret_cast<double*>(sm);                  // [8][32], reused for scale/shift afterwards
+    const int g = tid & (GN_GROUPS - 1), part = tid / GN_GROUPS;
     const int rows_per_c = (HW + nchunks - 1) / nchunks;
-    double n = 0.0, mu = 0.0, m2 = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-      const float* pp = partial + (((size_t)b * nchunks + k) * GN_GROUPS + tid) * 2;
+    const double N = (double)HW * (double)cpg;
+    double acc = 0.0;
+    for (int k = part; k < nchunks; k += 256 / GN_GROUPS) {
       const int rows_k = min(HW, (k + 1) * rows_per_c) - min(HW, k * rows_per_c);
-      const double nk = (double)rows_k * (double)cpg;
-      if (nk <= 0.0) continue;
-      const double nt = n + nk, d = (double)pp[0] - mu;
-      mu += d * nk / nt;
-      m2 += (double)pp[1] + d * d * n * nk / nt;
-      n = nt;
+      acc += (double)rows_k * (double)cpg * (double)partial[(((size_t)b * nchunks + k) * GN_GROUPS + g) * 2];
     }
-    mean[tid] = (float)mu;
-    rstd[tid] = (float)(1.0 / sqrt(m2 / n + (double)eps));
+    red[part * GN_GROUPS + g] = acc;
+    __syncthreads();
+    double mu = 0.0;
+#pragma unroll
+    for (int q = 0; q < 256 / GN_GROUPS; ++q) mu += red[q * GN_GROUPS + g];
+    mu /= N;
+    __syncthreads();
+    acc = 0.0;
+    for (int k = part; k < nchunks; k += 256 / GN_GROUPS) {
+      const int rows_k = min(HW, (k + 1) * rows_per_c) - min(HW, k * rows_per_c);
+      const float* pp = partial + (((size_t)b * nchunks + k) * GN_GROUPS + g) * 2;
+      const double d = (double)pp[0] - mu;
+      acc += (double)pp[1] + (double)rows_k * (double)cpg * d * d;
+    }
+    red[part * GN_GROUPS + g] = acc;
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+      double m2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 256 / GN_GROUPS; ++q) m2 += red[q * GN_GROUPS + tid];
+      mean[tid] = (float)mu;
+      rstd[tid] = (float)(1.0 / sqrt(m2 / N + (double)eps));
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int ch = tid; ch < C; ch += 256) {
     const int g = ch / cpg;
     const float w = gamma[ch] * rstd[g];
@@ -270,7 +291,7 @@ extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const
   const int nchunks = gn_nchunks(HW);
   const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
   const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
-  const size_t sm2 = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(float);
+  const size_t sm2 = (size_t)((2 * C > 512 ? 2 * C : 512) + 2 * GN_GROUPS) * sizeof(float);
   if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
   int nblk = (HW + TY * 8 - 1) / (TY * 8);                       // >= 8 rows per thread-row, <= 256 blocks per batch
   if (nblk < 1) nblk = 1;

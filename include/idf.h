@@ -55,16 +55,21 @@ const char* idf_build_info(void);
  * results are identical up to fp32 summation order).  Returns the previous value, or IDF_E_ARG for an unknown knob.
  *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256}-tile GEMM/conv kernel, 1 = automatic
  *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default.
- *   IDF_TUNE_GEMM_GEOM: geometry of that kernel: 0 = one 8-wave workgroup per CU on 256-row tiles (64-deep K-tiles, 2 LDS
- *   stages), 1 = two independent 4-wave workgroups per CU on 128-row tiles (32-deep K-tiles, 3 / 2 stages).  Env IDF_GEMM_GEOM.
+ *   IDF_TUNE_GEMM_GEOM: geometry / fill schedule of that kernel (env IDF_GEMM_GEOM): 0 = one 8-wave workgroup per CU on
+ *   256-row tiles (64-deep K-tiles, 2 LDS stages); waves 4-7 enqueue the next K-tile's LDS-DMA pieces from the middle of
+ *   their MFMAs (default); 1 = two independent 4-wave workgroups per CU on 128-row tiles (32-deep K-tiles, 3 / 2 stages);
+ *   2 = ping-pong: the two waves of a SIMD in opposite load / compute roles on 32-deep half-tiles, 4 stages;
+ *   3 / 4 / 5 = geometry 0 with waves 4-7 filling from the end / the middle of their K-tile / every wave spreading its
+ *   pieces between its MFMAs; 6 = geometry 0 with four 32-deep stages for the 256-wide tiles.
  *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; otherwise, when the shape qualifies, the
  *   64-queries-per-wave LDS-DMA kernel: 1 = classic online softmax, 2 = software-pipelined form (softmax of one query
  *   group beside the MFMAs of the other), 3 = lazy rescaling, 4 = pipelined + lazy (d in {24,40,56}, n0 % 8 == n1 % 8 == 0); 5 = variant 4 (attention4.hip: max-free
  *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid),
  *   6 = variant 4 with the plain block order (A/B of the XCD mapping), 7 / 8 = variant 4 with V^T fetched two tiles ahead;
- *   9 = variant 5 (attention5.hip: variant 4 as one 8-wave workgroup per 512 queries whose two waves per SIMD alternate
- *   between a matrix phase and a scalar phase), 10 = variant 5 with the plain block order, 11 = variant 5 with s_setprio 1
- *   in the matrix phases.  Initial value: env IDF_ATTN2 or default. */
+ *   9..14 = variant 5 (attention5.hip: variant 4 as one 8-wave workgroup per 512 queries whose two waves per SIMD alternate
+ *   between a matrix phase and a scalar phase): (value - 9) & 1 = plain block order instead of the XCD-aware one,
+ *   (value - 9) >> 1 = s_setprio 1 in no phase / the matrix phases / the scalar phases.
+ *   Initial value: env IDF_ATTN2 or default (5). */
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_GEOM = 2 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */

@@ -98,6 +98,11 @@ typedef struct {
   /* optional by-product: (mu, rstd) of every OUTPUT row (over its N columns, of the 16-bit-rounded values), for a
    * LayerNorm that follows -- out_stats = f32 [batch*M][2], eps = out_stats_eps.  NULL = none.  Not with GEGLU / OUT_F32. */
   float* out_stats; float out_stats_eps;
+  /* Self-normalising LN_ROW: with ln_stats == NULL the GEMM computes (mu, rstd) of A's rows itself -- in the K loop of the
+   * persistent kernel (two packed dot products per 16-B fragment chunk), by a statistics pass in front of the small-tile
+   * kernels -- with eps = ln_eps; K must be the whole LayerNorm row (K % 8 == 0, K <= 1536), batch 1.  ln_stats_out
+   * (f32 [M][2], or NULL) receives them, e.g. for the LN_COL projection of the same matrix that follows. */
+  float ln_eps; float* ln_stats_out;
 } idf_gemm_args;
 int idf_gemm(const idf_gemm_args* a, void* stream);
 

@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("batch", ci), ("strideA", ll), ("strideW", ll), ("strideO", ll), ("strideR", ll),
                 ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll),
                 ("ln_stats", vp), ("stride_ln_stats", ll), ("ln_c", vp), ("ln_d", vp),
-                ("out_stats", vp), ("out_stats_eps", cf)]
+                ("out_stats", vp), ("out_stats_eps", cf),
+                ("ln_eps", cf), ("ln_stats_out", vp)]
 
 
 class ConvArgs(C.Structure):

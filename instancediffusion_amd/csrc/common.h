@@ -30,6 +30,11 @@ template <> struct Elem<IDF_BF16> {
   static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
+  static constexpr unsigned ONES2 = 0x3f803f80u;                 // (1.0, 1.0)
+  // acc += a.lo * b.lo + a.hi * b.hi on the packed pair (one VALU op per two elements)
+  static __device__ __forceinline__ void dot2c(float& acc, unsigned a, unsigned b) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+  }
 };
 
 template <> struct Elem<IDF_F16> {
@@ -41,6 +46,10 @@ template <> struct Elem<IDF_F16> {
   }
   static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static constexpr unsigned ONES2 = 0x3c003c00u;
+  static __device__ __forceinline__ void dot2c(float& acc, unsigned a, unsigned b) {
+    asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
   }
 };
 

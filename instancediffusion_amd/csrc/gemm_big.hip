@@ -55,9 +55,11 @@ __device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigne
 // acc[a][b][4q+e] = D[n = a*32 + 8q + 4hi + e][m = b*32 + l31].  Two v_permlane32_swap per register pair
 // (q0 <-> q2, q1 <-> q3 between the lane halves) leave every lane with 16 CONSECUTIVE columns of its row:
 // n = a*32 + 16*hi + [0,16)  ->  two 16-B stores per (a, b), 16-B residual / rowbias loads, float4 bias loads.
-template <int DT, int BM, int BN, int TN, bool SPLIT>
+// LNS: the (mu, rstd) of the tile's A rows were computed in the K loop (lnm / lnr per 32-row fragment) instead of read.
+template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false>
 __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int slice, int tiles_n, int wm,
-                                             int wn, int l31, int hi, float gate) {
+                                             int wn, int l31, int hi, float gate, const float* lnm = nullptr,
+                                             const float* lnr = nullptr) {
   constexpr int WN = BN / 2;
   const int epi = p.epi;
   const int m_tile = seq / tiles_n;
@@ -72,6 +74,15 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
       v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
     }
   };
+  if constexpr (LNS) {                                      // leave the row statistics for an LN_COL consumer of A
+    if (p.ln_stats_out && n0 == 0 && wn == 0 && hi == 0) {
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = mw + b * 32 + l31;
+        if (m < p.M) *reinterpret_cast<f32x2*>(p.ln_stats_out + 2 * (size_t)m) = f32x2{lnm[b], lnr[b]};
+      }
+    }
+  }
   if constexpr (SPLIT) {                                    // fp32 partials of this K-slice; the reducer applies the epilogue
     static_for<0, TN, 1>([&](auto AI) {
       constexpr int a = decltype(AI)::value;
@@ -109,7 +120,9 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           f32x16 o;
           if (epi & IDF_EPI_LN_ROW) {               // LayerNorm folded in: rstd * (acc - mu * c) + (beta term + bias)
             const int mr = min(mw + b * 32 + l31, p.M - 1);
-            const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)mr);
+            f32x2 st;
+            if constexpr (LNS) st = f32x2{lnm[b], lnr[b]};
+            else st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)mr);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -156,7 +169,9 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
         const int m = mw + b * 32 + l31;
         if (m >= p.M) continue;
         if (epi & IDF_EPI_LN_ROW) {                 // v = rstd_m * (acc - mu_m * c[n]); the beta term arrives as bias
-          const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)m);
+          f32x2 st;
+          if constexpr (LNS) st = f32x2{lnm[b], lnr[b]};
+          else st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)m);
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] = st[1] * fmaf(-st[0], cs[j >> 2][j & 3], v[j]);
         }
@@ -217,7 +232,7 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
 //   <256, BN, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages).
 //   <128, BN, 32, 3|2>: TWO independent 4-wave workgroups per CU (their barriers, DMA waits and epilogues interleave on
 //   the SIMDs instead of coinciding); 64-B LDS rows, 16-B slot ^= (row >> 2) & 3.
-template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT>
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false>
 __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(const CoreParams p, const int tiles_total, const int skew) {
   constexpr int WN = BN / 2, TN = WN / 32;
   constexpr int NW = BM / 32;                              // waves per workgroup (8 or 4)
@@ -322,6 +337,7 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
   f32x16 acc[TN][TM];
   const int f_sw = swz(l31);                              // fragment rows are (multiple of 32) + l31
   int issued = 0;                                         // K-tiles enqueued so far
+  float lsx[TM], lsq[TM];                                 // LNS: per-lane partial sum / sum of squares of its A rows
   constexpr int NPOS = (BKT / 16) * TN;                   // (k-step, weight fragment) positions of a K-tile: TM MFMAs each
   // fill modes (`skew`, see the K loop): 0 burst before the MFMAs; 1 / 2: the second half of the workgroup bursts after the
   // middle / last position; 3: one piece every second position, the two halves on alternating positions
@@ -353,6 +369,15 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
         constexpr int pos = ks * TN + a;
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
+        if constexpr (LNS && a == 0) {                      // row sums of the A fragments this k-step multiplies: 16 VALU ops
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              Elem<DT>::dot2c(lsx[b], af[cur][b][w], Elem<DT>::ONES2);
+              Elem<DT>::dot2c(lsq[b], af[cur][b][w], af[cur][b][w]);
+            }
+        }
         if constexpr (pos / 2 < DPW) {
           if (mode == 3 && ((pos & 1) ^ par)) issue_piece(st_fill, IC<pos / 2>{});
         }
@@ -387,6 +412,8 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
       for (int b = 0; b < TM; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) { lsx[b] = 0.0f; lsq[b] = 0.0f; }
 
     for (int kt = 0; kt < nk; ++kt) {
       // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt
@@ -420,7 +447,18 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(c
 
     // epilogue of tile seq: no LDS, no barrier -- a wave that finishes its MFMAs early runs its epilogue while the other
     // wave of its SIMD is still in the K-loop
-    big_epilogue<DT, BM, BN, TN, SPLIT>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate);
+    float lnm[TM], lnr[TM];
+    if constexpr (LNS) {                                    // a row's 8-element chunks alternate between the lane halves
+      const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const float sx = lsx[b] + __shfl_xor(lsx[b], 32, 64), sq = lsq[b] + __shfl_xor(lsq[b], 32, 64);
+        const float mu = sx * inv_k;
+        lnm[b] = mu;
+        lnr[b] = rsqrtf(fmaxf(fmaf(-mu, mu, sq * inv_k), 0.0f) + p.ln_eps);
+      }
+    }
+    big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
   }
 }
 
@@ -683,12 +721,15 @@ int num_cu() {
   return g_num_cu;
 }
 
-template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT = false>
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false>
 int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
-  if constexpr (!SPLIT && BM == 256) {
+  if constexpr (!SPLIT && !LNS && BM == 256) {
     if (splitk > 1) return launch_big_cfg<DT, BM, BN, BKT, NSTG, CONV, true>(p, s, splitk);
   }
-  void (*kern)(const CoreParams, const int, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT>;
+  if constexpr (!SPLIT && !LNS && !CONV && BM == 256 && BKT == 64) {
+    if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BM, BN, BKT, NSTG, CONV, false, true>(p, s, 1);
+  }
+  void (*kern)(const CoreParams, const int, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS>;
   constexpr int smem = NSTG * (BM + BN) * BKT * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -755,19 +796,23 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if (!aligned16(p.out) || ((p.epi & IDF_EPI_RES) && !aligned16(p.res)) || ((p.epi & IDF_EPI_ROWBIAS) && !aligned16(p.rowbias)) ||
       ((p.epi & (IDF_EPI_BIAS | IDF_EPI_GEGLU)) && !aligned16(p.bias))) return IDF_BIG_UNSUPPORTED;
   if ((p.epi & (IDF_EPI_LN_ROW | IDF_EPI_LN_COL)) && (!aligned16(p.ln_c) || !aligned16(p.ln_stats))) return IDF_BIG_UNSUPPORTED;
+  // self-normalising LN_ROW (no statistics passed): only the lock-step 256-row kernel computes them in its K loop
+  const bool self_ln = (p.epi & IDF_EPI_LN_ROW) && !p.ln_stats;
+  if (self_ln && (conv || idf_big_geom() == 1 || idf_big_geom() == 2 || idf_big_geom() == 6)) return IDF_BIG_UNSUPPORTED;
+  const int geom = idf_big_geom();
   int bn = 0;
   if (geglu) bn = (p.N % 256 == 0) ? 256 : 0;
   else if (p.N % 320 == 0) bn = 320;
   else if (p.N % 256 == 0) bn = 256;
+  else if (p.N % 128 == 0 && geom != 1 && geom != 2 && !self_ln) bn = 128;
   if (!bn) return IDF_BIG_UNSUPPORTED;
-  const int geom = idf_big_geom();
   const int bm = geom == 1 ? 128 : 256;
   const long long slots = (long long)num_cu() * (geom == 1 ? 2 : 1);
   const long long tiles = (long long)(p.N / bn) * ((p.M + bm - 1) / bm);
   // split-K: when the tile grid leaves most CUs idle and K is long (the 8x8-level convs and ff-out GEMMs: 64 tiles of
   // 180..360 K-tiles), S slices per tile (S | K-tiles, >= 16 K-tiles each) leave fp32 partials in the caller's workspace
   int splitk = 1;
-  if (splitk_out && geom != 1 && geom != 2 && !geglu && p.ws && tiles * 2 <= slots) {
+  if (splitk_out && geom != 1 && geom != 2 && bn != 128 && !geglu && !self_ln && p.ws && tiles * 2 <= slots) {
     const int nkt = p.K / BK;
     for (int cand = (int)(slots / tiles); cand >= 2; --cand) {
       if (nkt % cand || nkt / cand < 16) continue;
@@ -807,6 +852,10 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if (geom == 6 && bn == 256 && splitk == 1) {                                                                            \
     if (conv) return launch_big_cfg<DT, 256, 256, 32, 4, true>(p, s);                                                     \
     return launch_big_cfg<DT, 256, 256, 32, 4, false>(p, s);                                                              \
+  }                                                                                                                       \
+  if (bn == 128) {                       /* 128-wide tiles (the VAE's 128-channel convs at 512^2): 3 stages of 48 KB */  \
+    if (conv) return launch_big_cfg<DT, 256, 128, 64, 3, true>(p, s);                                                     \
+    return launch_big_cfg<DT, 256, 128, 64, 3, false>(p, s);                                                              \
   }                                                                                                                       \
   if (conv) return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, true>(p, s, splitk) : launch_big_cfg<DT, 256, 256, 64, 2, true>(p, s, splitk);     \
   return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, false>(p, s, splitk) : launch_big_cfg<DT, 256, 256, 64, 2, false>(p, s, splitk);

@@ -599,9 +599,20 @@ int launch(const CoreParams& p, int batch, hipStream_t s) {
       return rc;
     }
   }
+  // self-normalising LN_ROW on the small-tile kernels: the statistics pass runs first (into the caller's buffer when it
+  // wants them, else into the head of the workspace -- such GEMMs never split K: their K is one activation row)
+  CoreParams q = p;
+  if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) {
+    float* st = p.ln_stats_out ? p.ln_stats_out : p.ws;
+    if (!st || (!p.ln_stats_out && p.ws_bytes < (size_t)p.M * 2 * sizeof(float))) return IDF_E_ARG;
+    const int rc = idf_row_stats(p.A, p.lda, st, p.M, p.K, p.ln_eps, DT, s);
+    if (rc) return rc;
+    q.ln_stats = st; q.stride_ln_stats = 0;
+    if (!p.ln_stats_out) { q.ws = nullptr; q.ws_bytes = 0; }
+  }
   // (64x64 tiles for short-K dense GEMMs were measured 6-20 % slower: profiles/r01_diag_B18_tile64_ab.log)
-  if (geglu || (p.N % 128 == 0) || p.N > 1024 || (use_wide && p.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(p, batch, s);
-  return launch_cfg<DT, 128, 64, 64, 32, CONV>(p, batch, s);
+  if (geglu || (q.N % 128 == 0) || q.N > 1024 || (use_wide && q.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(q, batch, s);
+  return launch_cfg<DT, 128, 64, 64, 32, CONV>(q, batch, s);
 }
 
 }  // namespace
@@ -652,7 +663,13 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   const int batch = a->batch > 0 ? a->batch : 1;
   if (a->epi & (IDF_EPI_LN_ROW | IDF_EPI_LN_COL)) {
     if ((a->epi & IDF_EPI_LN_ROW) && (a->epi & IDF_EPI_LN_COL)) return IDF_E_ARG;
-    if (!a->ln_stats || !a->ln_c) return IDF_E_ARG;
+    if (!a->ln_c) return IDF_E_ARG;
+    if (!a->ln_stats) {
+      // self-normalising LN_ROW: statistics of A's rows computed by the GEMM itself (K = the whole row), unbatched
+      if (!(a->epi & IDF_EPI_LN_ROW) || batch != 1 || (a->K % 8) || a->K > 1536 || !(a->ln_eps > 0.0f)) return IDF_E_ARG;
+      if (a->ln_stats_out && (((uintptr_t)a->ln_stats_out) & 7u)) return IDF_E_ALIGN;
+      p.ln_eps = a->ln_eps; p.ln_stats_out = a->ln_stats_out;
+    }
     if ((a->epi & IDF_EPI_LN_ROW) && !(a->epi & IDF_EPI_BIAS)) return IDF_E_ARG;       // the beta term travels as bias
     if ((a->epi & IDF_EPI_LN_COL) && (!a->ln_d || (a->epi & IDF_EPI_GEGLU))) return IDF_E_ARG;
     if ((((uintptr_t)a->ln_stats) & 7u) || (a->stride_ln_stats & 1)) return IDF_E_ALIGN;

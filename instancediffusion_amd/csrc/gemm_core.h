@@ -17,6 +17,9 @@ struct CoreParams {
   // LayerNorm folded into the GEMM (IDF_EPI_LN_ROW / IDF_EPI_LN_COL, include/idf.h): (mu, rstd) pairs of the normalised
   // operand's rows, the column sums c of the gamma-folded weight and (LN_COL) the beta term d
   const float* ln_stats; long long stride_ln_stats; const float* ln_c; const float* ln_d;
+  // LN_ROW with ln_stats == nullptr: the kernel computes (mu, rstd) of A's rows itself (eps = ln_eps) and, when
+  // ln_stats_out != nullptr, leaves them there ([M][2]) for an LN_COL consumer of the same matrix
+  float ln_eps; float* ln_stats_out;
 };
 
 constexpr int BK = 64;

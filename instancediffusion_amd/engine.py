@@ -22,6 +22,10 @@ import torch
 from .host.attention import SpatialTransformer
 from .host.unet import Downsample, ResBlock, UNetModel, Upsample
 
+# LayerNorm statistics of the folded GEMMs (A/B switch, env IDF_LN_SELF): 0 = every producer of the residual stream emits them
+# (out_stats pass), 2 = every LN_ROW consumer sums its own A rows, 1 (default) = q/k and cross-q sum their own, the GEGLU GEMMs
+# take them from the producer.
+LN_SELF_MODE = int(os.environ.get("IDF_LN_SELF", "1"))
 OBJ_TOKENS = 184
 MASK_RES = 64                  # the reference applies the fuser mask only when H*W == 64*64 (attention.py:195)
 
@@ -512,7 +516,13 @@ class UNetEngine:
         into the projections (``_fold_ln``).  Returns the attention output [B, N, C] (pre out-proj).
         ``vis``: (qbits, kbits0, kbits1) visibility words of the masked gated self-attention, or None."""
         ops = self.ops
-        qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(st, a["cqk"])).view(B, N, 2 * C)
+        # the q/k projection computes the LayerNorm statistics of y's rows in its own K loop and leaves them in st for the
+        # transposed-V projection below
+        if self._ln_self(C):
+            qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(None, a["cqk"]),
+                          ln_stats_out=st).view(B, N, 2 * C)
+        else:
+            qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(st, a["cqk"])).view(B, N, 2 * C)
         if self.vt_global and N % 64 == 0 and N >= 1024:
             # V^T in the batch-interleaved image [C][B][N]: ONE unbatched GEMM  V^T = Wv . X^T  over all B*N tokens
             # (M = C, N = B*N: served by the persistent big-tile kernel) instead of B small batched ones; the
@@ -536,39 +546,53 @@ class UNetEngine:
                           n1=OBJ_TOKENS, qbits=vis[0], kbits0=vis[1], kbits1=vis[2])
         return att
 
+    @staticmethod
+    def _ln_self(C):
+        """Do the q/k and cross-q projections of a C-channel level sum their own A rows?  Mode 1: only where the projection
+        is HBM-bound (C = 320: the in-loop v_dot2c sums share the matrix pipe and cost 12 % on the MFMA-bound levels, more
+        than the 8-B-per-row statistics pass they replace there)."""
+        return LN_SELF_MODE == 2 or (LN_SELF_MODE == 1 and C <= 320)
+
     def _ff(self, f, y, st, M, C, gate=None, out_stats=None):
-        """y += [gate *] GEGLU-FF(LN(y)); the LayerNorm is folded into the first GEMM (statistics st)."""
+        """y += [gate *] GEGLU-FF(LN(y)); the LayerNorm is folded into the first GEMM (statistics st, left by the GEMM that
+        produced y: a GEGLU GEMM has 8-16 column tiles per row block, each of which would repeat the in-loop row sums --
+        measured +15 % on those launches -- so here the separate 8-B-per-row pass is the cheaper form)."""
         ops = self.ops
-        mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True, ln_row=(st, f["c1"]))
+        mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True,
+                       ln_row=(None if LN_SELF_MODE == 2 else st, f["c1"]))
         return ops.gemm(mid, f["l2"].w, y, bias=f["l2"].b, res=y, gate=gate, out_stats=out_stats)
 
     def _st(self, p, x, cond: Cond, fuser_on: bool):
-        """SpatialTransformer (attention.py:366-379).  No LayerNorm kernel runs: every GEMM that writes the residual stream y
-        also emits (mu, rstd) of its output rows (``out_stats``) and every GEMM that reads LN(y) reads y itself and applies
-        them in its epilogue against gamma-folded weights."""
+        """SpatialTransformer (attention.py:366-379).  No LayerNorm kernel runs: every GEMM that reads LN(y) reads y itself
+        against gamma-folded weights and applies (mu, rstd) in its epilogue.  The q/k and cross-q projections sum their A
+        rows in their own K loop (the q/k one hands the statistics to the transposed-V projection); the GEGLU GEMMs take
+        them from the out-projection that wrote y (``out_stats``: an 8-B-per-row pass inside that idf_gemm call)."""
         ops = self.ops
         B, H, W, C = x.shape
         N, M = H * W, B * H * W
         g = ops.groupnorm(x, self.buf("gn", x.shape), p["norm"][0], p["norm"][1], 1e-6, False)
         st = self.buf("st.stats", (M, 2), torch.float32)
-        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b, out_stats=st)
+        own = self._ln_self(C)
+        pre, ffs = (None if own else st), (st if LN_SELF_MODE <= 1 else None)   # which producers emit statistics
+        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b, out_stats=pre)
         # --- self attention (attention.py:334): LN norm1
         att = self._self_attn(p["attn1"], y, st, B, N, C)
-        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y, out_stats=st)
+        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y, out_stats=pre)
         # --- gated self attention over [visual ; grounding tokens] (attention.py:304-311): LN fuser.norm1 / norm2
         i = p["idx"]
         if fuser_on:
             vis = cond.vis if (cond.vis and N == MASK_RES * MASK_RES) else None
             att = self._self_attn(p["f_attn"], y, st, B, N, C, kv_extra=(cond.k_obj[i], cond.vt_obj[i]), vis=vis)
             ops.gemm(att.view(M, C), p["f_attn"]["out"].w, y, bias=p["f_attn"]["out"].b, res=y, gate=self.gates[i, 0:1],
-                     out_stats=st)
-            self._ff(p["f_ff"], y, st, M, C, gate=self.gates[i, 1:2], out_stats=st)
+                     out_stats=ffs)
+            self._ff(p["f_ff"], y, st, M, C, gate=self.gates[i, 1:2], out_stats=pre)
         # --- cross attention (attention.py:336): LN norm2 on the query side
         a2 = p["attn2"]
-        q = ops.gemm(y, a2["wq"], self.buf("st.q", (M, C)), bias=a2["dq"], ln_row=(st, a2["cq"])).view(B, N, C)
+        q = ops.gemm(y, a2["wq"], self.buf("st.q", (M, C)), bias=a2["dq"],
+                     ln_row=(None if own else st, a2["cq"])).view(B, N, C)
         att = self.buf("st.att", (B, N, C))
         ops.attention(q, cond.k_ctx[i], cond.vt_ctx[i], cond.n_ctx, att, self.heads)
-        ops.gemm(att.view(M, C), a2["out"].w, y, bias=a2["out"].b, res=y, out_stats=st)
+        ops.gemm(att.view(M, C), a2["out"].w, y, bias=a2["out"].b, res=y, out_stats=ffs)
         # --- feed forward (attention.py:337): LN norm3
         self._ff(p["ff"], y, st, M, C)
         # --- proj_out + x_in (attention.py:378-379), in place on the block input

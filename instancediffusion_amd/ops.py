@@ -67,7 +67,8 @@ class HipOps:
 
     # ------------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None,
-             act: Optional[str] = None, geglu: bool = False, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5):
+             act: Optional[str] = None, geglu: bool = False, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5,
+             ln_eps=1e-5, ln_stats_out=None):
         """out[..,M,N] = epi(a[..,M,K] @ w[..,N,K]^T).  2-D or batched 3-D views; a/w may be shared (2-D) in a
         batched call.  geglu: ``w``/``bias`` are in the packed [32 value | 32 gate] row order, out has N/2 cols.
         ln_row = (stats [.., M, 2], c [N]): ``a`` is the RAW input of a LayerNorm whose gamma is folded into ``w`` and whose
@@ -108,8 +109,13 @@ class HipOps:
         ln_stats = ln_c = ln_d = None
         s_ln = 0
         if ln_row is not None:
-            ln_stats, ln_c = ln_row
-            assert bias is not None and ln_stats.shape[-2] == M and ln_c.numel() == N and ln_stats.dtype == torch.float32
+            ln_stats, ln_c = ln_row                     # ln_stats None: the GEMM computes the row statistics itself
+            assert bias is not None and ln_c.numel() == N
+            assert ln_stats is None or (ln_stats.shape[-2] == M and ln_stats.dtype == torch.float32)
+            if ln_stats is None:
+                assert not batched
+                if ln_stats_out is not None:
+                    assert ln_stats_out.is_contiguous() and ln_stats_out.dtype == torch.float32 and ln_stats_out.numel() == 2 * M
             epi |= EPI_LN_ROW
         elif ln_col is not None:
             ln_stats, ln_c, ln_d = ln_col
@@ -132,7 +138,8 @@ class HipOps:
             epi=epi, dtype=self.dt, ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES,
             ln_stats=None if ln_stats is None else ln_stats.data_ptr(), stride_ln_stats=s_ln,
             ln_c=None if ln_c is None else ln_c.data_ptr(), ln_d=None if ln_d is None else ln_d.data_ptr(),
-            out_stats=None if out_stats is None else out_stats.data_ptr(), out_stats_eps=float(out_stats_eps))
+            out_stats=None if out_stats is None else out_stats.data_ptr(), out_stats_eps=float(out_stats_eps),
+            ln_eps=float(ln_eps), ln_stats_out=None if ln_stats_out is None else ln_stats_out.data_ptr())
         _lib.check(self.lib.idf_gemm(C.byref(args), self._stream()), "idf_gemm")
         return out
 

@@ -36,7 +36,7 @@ class EmulOps:
 
     # ----------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None, act=None, geglu=False,
-             ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5):
+             ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5, ln_eps=1e-5, ln_stats_out=None):
         self._count("gemm")
         assert a.dtype == self.dtype and w.dtype == self.dtype
         assert a.shape[-1] % 64 == 0, "K % 64"
@@ -44,6 +44,11 @@ class EmulOps:
         if ln_row is not None:                         # include/idf.h IDF_EPI_LN_ROW: rstd_m * (acc - mu_m c_n) (+ d as bias)
             st, c = ln_row
             assert bias is not None
+            if st is None:                             # self-normalising: statistics of a's rows (the 16-bit values)
+                af = a.float()
+                st = torch.stack([af.mean(-1), torch.rsqrt(af.var(-1, unbiased=False) + ln_eps)], -1)
+                if ln_stats_out is not None:
+                    ln_stats_out.reshape(-1, 2).copy_(st.reshape(-1, 2))
             acc = st[..., 1:2] * (acc - st[..., 0:1] * c.reshape(1, -1))
         if ln_col is not None:                         # IDF_EPI_LN_COL: rstd_n * (acc - c_m mu_n) + d_m
             st, c, d = ln_col

@@ -686,6 +686,42 @@ def test_gemm_layernorm_folded(ops, M, N, K, mode):
     assert mx < BF16_TOL and err < BF16_TOL / 2
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(65536, 640, 320, False), (65536 + 77, 320, 320, False), (16384, 1280, 640, False),
+                                         (4096, 1280, 1280, False), (65536, 2560, 320, True), (16384, 5120, 640, True),
+                                         (300, 640, 320, False), (200, 2560, 320, True), (1000, 192, 64, False)])
+def test_gemm_layernorm_self_stats(ops, M, N, K, geglu):
+    """LN_ROW without statistics: the persistent kernel sums its A rows in the K loop (v_dot2c on the fragments it
+    multiplies), the small-tile path runs the statistics pass first.  Against the fp32 LayerNorm -> Linear reference, with a
+    row offset (|mean| ~ 2 x std) so that E[x^2] - mu^2 is exercised; the emitted statistics are checked too."""
+    import torch.nn.functional as F
+    from instancediffusion_amd.engine import pack_geglu
+    gamma, beta = 1 + 0.2 * gen((K,), 91), 0.3 * gen((K,), 92)
+    x = to16(gen((M, K), 93) * 1.5 + 3.0 * gen((M, 1), 94))
+    w, b = gen((N, K), 95, K ** -0.5), 0.2 * gen((N,), 96)
+    ln = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+    st = ops.empty((M, 2), torch.float32)
+    if geglu:
+        wp, dp = pack_geglu(w * gamma[None, :], b + w @ beta)
+        w16 = to16(wp)
+        out = ops.gemm(dev(x), dev(w16), ops.empty((M, N // 2)), bias=dev(dp), geglu=True, ln_row=(None, dev(w16.float().sum(1))),
+                       ln_stats_out=st)
+        h = ln @ w.t() + b
+        want = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+    else:
+        w16, c, d = _fold(w, gamma, beta, b)
+        out = ops.gemm(dev(x), dev(w16), ops.empty((M, N)), bias=dev(d), ln_row=(None, dev(c)), ln_stats_out=st)
+        want = ln @ w.t() + b
+    torch.cuda.synchronize()
+    err, mx = rel_rms(out, want), relmax(out, want)
+    xf = x.float()
+    mu_err = float((st[:, 0].cpu() - xf.mean(-1)).abs().max())
+    rs_rel = float((st[:, 1].cpu() / torch.rsqrt(xf.var(-1, unbiased=False) + 1e-5) - 1).abs().max())
+    print(f"[parity] gemm LN self-stats M{M} N{N} K{K} geglu={geglu}: rel-rms {err:.3e} max-rel {mx:.3e}; "
+          f"mu abs err {mu_err:.2e}, rstd rel err {rs_rel:.2e}")
+    assert mx < BF16_TOL and err < BF16_TOL / 2
+    assert mu_err < 1e-4 and rs_rel < 1e-4
+
+
 def test_gemm_out_stats(ops):
     """The by-product (mu, rstd) of the OUTPUT rows equals the statistics of the 16-bit output actually written."""
     M, N, K = 4096, 320, 320

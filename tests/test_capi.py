@@ -56,6 +56,19 @@ def test_argument_validation_without_gpu():
     assert lib.idf_pointwise_nchw(None, None, None, None, 1, 4, 4, 16, 1.0, None) == -1
     with pytest.raises(_lib.IdfError):
         _lib.check(-2, "x")
+    # self-normalising LN_ROW (ln_stats == NULL): rejected before any launch when batched, without eps, on rows longer
+    # than the statistics kernels hold, or with a misaligned statistics output (fake, never dereferenced pointers)
+    def ln_args(**kw):
+        g = _lib.GemmArgs(A=0x10000, W=0x20000, out=0x30000, bias=0x40000, M=256, N=320, K=320, lda=320, ldw=320, ldo=320,
+                          batch=1, epi=_lib.EPI_BIAS | _lib.EPI_LN_ROW, dtype=0, ln_c=0x50000, ln_eps=1e-5)
+        for k, v in kw.items():
+            setattr(g, k, v)
+        return g
+    assert lib.idf_gemm(ctypes.byref(ln_args(batch=2, strideA=81920, strideO=81920)), None) == -1
+    assert lib.idf_gemm(ctypes.byref(ln_args(ln_eps=0.0)), None) == -1
+    assert lib.idf_gemm(ctypes.byref(ln_args(K=1600, lda=1600, ldw=1600)), None) == -1
+    assert lib.idf_gemm(ctypes.byref(ln_args(ln_stats_out=0x60004)), None) == -2
+    assert lib.idf_gemm(ctypes.byref(ln_args(epi=_lib.EPI_LN_ROW)), None) == -1          # the beta term travels as bias
 
 
 def test_schema_matches_reference():

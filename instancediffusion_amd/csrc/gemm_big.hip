@@ -17,6 +17,13 @@
 // same lane); v_permlane32_swap then exchanges register pairs between the two lane halves so that a lane owns 16
 // consecutive columns of its row: 16-B stores / residual / rowbias accesses without an LDS transposition or a barrier.
 //
+// Round 2 (profiles/r02_*): the LDS-DMA pieces are inline assembly and the second half of the workgroup enqueues them from
+// the middle of its K-tile (fill schedule, see the K loop); split-K work items for grids that leave most CUs idle
+// (SPLIT); LayerNorm folded into the epilogue (IDF_EPI_LN_ROW / LN_COL) with the row statistics optionally summed in the
+// K loop itself (LNS); 128-wide tiles with three stages; a role-split ping-pong variant of the same tile
+// (gemm_kernel_pp, geometry 2: measured slower, kept for A/B).  What bounds the K loop: tools/ubench/dma_rate.hip --
+// a wave moves 5.6 B/clk from L2 into LDS, a CU 34 B/clk, the 256 x 320 tile needs 28.8 B/clk at 100 % MFMA.
+//
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops 2*M*N*K.  LDS image and XOR swizzle are the ones
 // of gemm_kernel_dma (linear 128-B rows, 16-B slot ^= (row >> 1) & 7 applied on the global source address).
 #include "gemm_core.h"

@@ -695,7 +695,7 @@ int launch_attn2(const AttnParams& p, int B, hipStream_t s) {
 
 }  // namespace
 
-long long idf_stat_attn2_launches = 0;
+std::atomic<long long> idf_stat_attn2_launches{0};
 
 int idf_launch_attn2(const AttnParams& p, int B, int dtype, hipStream_t s) {
   if (p.d != 24 && p.d != 40 && p.d != 56) return IDF_ATTN2_UNSUPPORTED;

@@ -24,7 +24,8 @@ struct AttnParams {
 #ifndef IDF_ATTN2_DEFAULT
 #define IDF_ATTN2_DEFAULT 5
 #endif
-extern long long idf_stat_attn2_launches;
+#include <atomic>
+extern std::atomic<long long> idf_stat_attn2_launches;   // process-global launch counter (idf_get_stat)
 int idf_attn2_mode();
 int idf_attn2_set_mode(int v);
 int idf_launch_attn2(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);

@@ -782,7 +782,7 @@ int g_pp_dl = -1;
 
 }  // namespace
 
-long long idf_stat_big_launches = 0;
+std::atomic<long long> idf_stat_big_launches{0};
 
 int idf_big_geom() {
   if (g_geom == -2) { const char* e = getenv("IDF_GEMM_GEOM"); g_geom = e ? atoi(e) : IDF_GEMM_GEOM_DEFAULT; }

@@ -636,8 +636,8 @@ extern "C" int idf_set_tuning(int knob, int value) {
 }
 
 extern "C" long long idf_get_stat(int stat) {
-  if (stat == IDF_STAT_GEMM_BIG_LAUNCHES) return idf_stat_big_launches;
-  if (stat == IDF_STAT_ATTN2_LAUNCHES) return idf_stat_attn2_launches;
+  if (stat == IDF_STAT_GEMM_BIG_LAUNCHES) return idf_stat_big_launches.load();
+  if (stat == IDF_STAT_ATTN2_LAUNCHES) return idf_stat_attn2_launches.load();
   return -1;
 }
 

@@ -2,6 +2,7 @@
 // the launch parameter block, the K-tile depth and the 8-column epilogue.
 #pragma once
 #include "common.h"
+#include <atomic>
 
 namespace idfcore {
 
@@ -120,7 +121,7 @@ __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, in
 #ifndef IDF_GEMM_GEOM_DEFAULT
 #define IDF_GEMM_GEOM_DEFAULT 0
 #endif
-extern long long idf_stat_big_launches;
+extern std::atomic<long long> idf_stat_big_launches;     // process-global launch counter (idf_get_stat)
 int idf_big_geom();
 int idf_big_set_geom(int v);
 // *splitk_out > 1 on return: the kernel left fp32 partials of that many K-slices in p.ws; the caller runs the reducer

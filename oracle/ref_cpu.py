@@ -99,11 +99,14 @@ def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, mask: Opt
     qh = q.view(B, N, heads, d).permute(0, 2, 1, 3)
     kh = k.view(B, M, heads, d).permute(0, 2, 1, 3)
     vh = v.view(B, M, heads, d).permute(0, 2, 1, 3)
-    s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
-    if mask is not None:
+    if mask is None:
+        # the reference's efficient path IS this call (attention.py:140,143,263,266); on CPU it is also ~2x faster than the
+        # explicit form below, which matters only for bench.py's cpu_baseline (profiles/r02_cpu_reference_vs_port.json)
+        o = F.scaled_dot_product_attention(qh, kh, vh)
+    else:
+        s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
         s = s.masked_fill(mask <= 0.0, float("-inf"))
-    p = torch.softmax(s, dim=-1)
-    o = torch.matmul(p, vh)
+        o = torch.matmul(torch.softmax(s, dim=-1), vh)
     return o.permute(0, 2, 1, 3).reshape(B, N, C)
 
 

@@ -187,11 +187,13 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int nvalid = p.n[seg] - kv0;            // >= 1
+    const bool two = nvalid > 32;                 // a tail of <= 32 keys (the 13 of the 77 text tokens): only the first half-tile
 
     // ---- S^T = K Q^T  (2 tiles of 32 kv rows)
     f32x16 s[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
+      if (st == 1 && !two) break;
       const unsigned short* kf = Kc + (st * 32 + l31) * KSTR + hi * 8;
       {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -207,18 +209,21 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     // ---- mask the tail, running max.  s[st][r]: kv = kv0 + st*32 + (r&3) + 8*(r>>2) + 4*hi
     if (nvalid < KVT) {
 #pragma unroll
-      for (int st = 0; st < 2; ++st)
+      for (int st = 0; st < 2; ++st) {
+        if (st == 1 && !two) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           s[st][r] = (kv >= nvalid) ? -INFINITY : s[st][r];
         }
+      }
     }
     if (MASK) {
       const unsigned* bw = Bl + (t & 1) * KVT;
       const int self_kv = (seg == 0) ? (qrow - kv0) : -1;          // tile-local index of the query's own token
 #pragma unroll
-      for (int st = 0; st < 2; ++st)
+      for (int st = 0; st < 2; ++st) {
+        if (st == 1 && !two) break;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           const int kvb = st * 32 + 8 * q4 + 4 * hi;
@@ -229,12 +234,15 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
             s[st][4 * q4 + e] = ok ? s[st][4 * q4 + e] : -INFINITY;
           }
         }
+      }
     }
     float mx = s[0][0];
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < 2; ++st) {
+      if (st == 1 && !two) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float m_new = fmaxf(m_run, mx * c);            // c > 0
     // MASK: every key seen so far may be masked for this query (m_new = -inf): keep exp2 arguments finite
@@ -244,13 +252,15 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     m_new = m_use;
     float rs = 0.0f;
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < 2; ++st) {
+      if (st == 1 && !two) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = __builtin_amdgcn_exp2f(fmaf(s[st][r], c, -m_new));
         s[st][r] = pv;
         if (!MFMASUM) rs += pv;
       }
+    }
     if (!MFMASUM) l_run = l_run * alpha + rs;
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     // ---- O^T += V^T P^T.  K-step (st, k2): P regs 8*k2..8*k2+7 of tile st  <->  kv = st*32 + 16*k2 + 4*hi + {0..3, 8..11}
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
+      if (st == 1 && !two) break;
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
         u32x4 pf;

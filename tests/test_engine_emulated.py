@@ -67,6 +67,29 @@ def test_engine_forward_vs_reference(tag, dtype, tol):
         assert cases.rel_rms(both[:B], gold["eps_cond"]) < tol and cases.rel_rms(both[B:], gold["eps_uncond"]) < tol
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_layernorm_statistics_sources_agree(mode, monkeypatch):
+    """The three ways the LN-folded GEMMs get (mu, rstd) -- from the producer's out_stats pass (mode 0), summed by the
+    consumer itself (mode 2), the default mix (mode 1) -- are the same arithmetic on the same rows: the emulated forward
+    must agree to fp32 round-off whichever buffers carry them (catches a stale or clobbered `st.stats`)."""
+    from instancediffusion_amd import engine as engine_mod
+    gold = cases.load_golden("tiny_mask")
+    meta = gold["meta"]
+    cfg = cases.cfg_for(meta["cfg"], meta["variant"])
+    inp = cases.build_inputs(meta)
+    model = build_model(cfg)
+    g = GroundingNetInput().prepare(inp["gb"])
+    outs = {}
+    for m in (1, mode):
+        monkeypatch.setattr(engine_mod, "LN_SELF_MODE", m)
+        eng = UNetEngine(model, ops=EmulOps(torch.float32), use_graphs=False)
+        with torch.no_grad():
+            cond = eng.prepare_cond(inp["context"], g)
+            outs[m] = eng.forward_cond(inp["x"], inp["t"], cond).clone()
+    assert cases.rel_rms(outs[mode], outs[1]) < 1e-5
+    assert cases.rel_rms(outs[mode], gold["eps_cond"]) < 3e-4
+
+
 def test_fuser_skipped_at_scale_zero_is_exact():
     gold = cases.load_golden("tiny_box")
     meta = gold["meta"]

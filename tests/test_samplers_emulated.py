@@ -137,3 +137,35 @@ def test_mis_sharded_world2_gloo(sharding):
     assert 0 < r0 < single and 0 < r1 < single, (single, r0, r1)
     assert max(r0, r1) <= 0.70 * single, "neither rank may carry (almost) the whole job"
     assert r0 + r1 <= 1.15 * single, "sharding must not duplicate work beyond the hoisted first evaluation"
+
+
+def test_mis_sharded_world3_more_ranks_than_images_gloo():
+    """Strong-scaling shape: MORE ranks (3) than images (2), `instance` ownership -- the N+1 trajectories of an image are
+    spread over the ranks, one rank owns no image in phase 2 and still has to take part in every collective.  All ranks
+    must return the reference trajectory, bit-identical to each other, with the attention rows split three ways."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    port = 29500 + (os.getpid() % 500) + 13
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q, "instance")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(o), n) for r, o, n in res]
+    for p in procs:
+        p.join(timeout=60)
+    gold = cases.load_golden("tiny_box")
+    assert gold["meta"]["batch"] < world
+    for rank, out, n_attn in res:
+        assert cases.rel_rms(out, gold["mis"]) < 5e-3, rank
+        assert torch.equal(out, res[0][1]), rank
+    gold, meta, inp, model, gi, diffusion = setup("tiny_box")
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
+                              set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+    sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"], guidance_scale=7.5)
+    single = sampler.engine.ops.rows["attention"]
+    rows = [n for _, _, n in res]
+    print(f"[world 3, instance] attention rows: single process {single}, per rank {rows}")
+    assert all(0 < n < single for n in rows), (single, rows)
+    assert max(rows) <= 0.60 * single and sum(rows) <= 1.30 * single, (single, rows)

@@ -739,6 +739,31 @@ def test_gemm_layernorm_self_stats(ops, M, N, K, geglu):
     assert mu_err < 1e-4 and rs_rel < 1e-4
 
 
+def test_gemm_layernorm_self_stats_f16():
+    """The fp16 instantiation of the in-loop row sums (v_dot2c_f32_f16) on the persistent kernel."""
+    import torch.nn.functional as F
+    from instancediffusion_amd.ops import HipOps
+    o16 = HipOps(torch.float16)
+    M, N, K = 65536, 640, 320
+    gamma, beta = 1 + 0.2 * gen((K,), 91), 0.3 * gen((K,), 92)
+    x = (gen((M, K), 93) * 1.5 + 3.0 * gen((M, 1), 94)).half()
+    w, b = gen((N, K), 95, K ** -0.5), 0.2 * gen((N,), 96)
+    w16 = (w * gamma[None, :]).half()
+    c, d = w16.float().sum(1), w @ beta + b
+    st = o16.empty((M, 2), torch.float32)
+    out = o16.gemm(dev(x), dev(w16), o16.empty((M, N)), bias=dev(d), ln_row=(None, dev(c)), ln_stats_out=st)
+    torch.cuda.synchronize()
+    want = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    xf = x.float()
+    mu_err = float((st[:, 0].cpu() - xf.mean(-1)).abs().max())
+    rs_rel = float((st[:, 1].cpu() / torch.rsqrt(xf.var(-1, unbiased=False) + 1e-5) - 1).abs().max())
+    err, mx = rel_rms(out, want), relmax(out, want)
+    print(f"[parity] gemm LN self-stats fp16 M{M} N{N} K{K}: rel-rms {err:.3e} max-rel {mx:.3e}; mu abs err {mu_err:.2e}, "
+          f"rstd rel err {rs_rel:.2e}")
+    assert mx < 2.0 ** -9 and err < 2.0 ** -10
+    assert mu_err < 1e-4 and rs_rel < 1e-4
+
+
 def test_gemm_out_stats(ops):
     """The by-product (mu, rstd) of the OUTPUT rows equals the statistics of the 16-bit output actually written."""
     M, N, K = 4096, 320, 320

@@ -26,6 +26,8 @@ from .host.unet import Downsample, ResBlock, UNetModel, Upsample
 # (out_stats pass), 2 = every LN_ROW consumer sums its own A rows, 1 (default) = q/k and cross-q sum their own, the GEGLU GEMMs
 # take them from the producer.
 LN_SELF_MODE = int(os.environ.get("IDF_LN_SELF", "1"))
+if LN_SELF_MODE not in (0, 1, 2):          # any other value would leave LN_ROW consumers reading statistics nobody wrote
+    raise ValueError(f"IDF_LN_SELF={LN_SELF_MODE}: must be 0, 1 or 2")
 OBJ_TOKENS = 184
 MASK_RES = 64                  # the reference applies the fuser mask only when H*W == 64*64 (attention.py:195)
 

@@ -41,13 +41,32 @@ class _Bag:
         raise pickle.PicklingError("placeholder object")
 
 
-# Globals a reference checkpoint legitimately pickles: tensors / storages (torch), containers (collections, builtins
-# data types), numpy scalars, and the OmegaConf node classes of ``config_dict`` (turned into attribute bags, never
-# imported).  Everything else is refused: a checkpoint is data, it must not be able to name arbitrary callables.
+# Globals a reference checkpoint legitimately pickles, as EXACT (module, name) pairs: the tensor / parameter rebuild
+# functions and storage classes torch.save emits, torch dtypes, containers, numpy array / scalar reconstruction, and
+# the two plain-data classes training scripts leave in ``config_dict`` / ``args``.  A module ROOT is never enough:
+# torch.utils.collect_env.run, torch.hub.load or numpy.testing._private.utils.runstring are all "inside torch / numpy"
+# and execute what a pickle hands them.  The OmegaConf node classes of ``config_dict`` and the
+# pytorch_lightning callback objects of official SD checkpoints become inert attribute bags (never imported, never
+# called).  Everything else is refused.
 _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
                   "complex", "slice", "range", "object"}
-_SAFE_MODULE_ROOTS = ("torch", "collections", "numpy", "typing", "pathlib", "argparse", "enum")
-_BAG_MODULE_ROOTS = ("omegaconf",)
+_TORCH_STORAGES = {"DoubleStorage", "FloatStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+                   "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "ComplexFloatStorage",
+                   "ComplexDoubleStorage", "UntypedStorage"}
+_SAFE_GLOBALS = {
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Tensor"), ("torch", "Size"), ("torch", "device"), ("torch.nn.parameter", "Parameter"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("_codecs", "encode"),                          # numpy arrays pickled with protocol 2 carry their bytes through it
+    ("typing", "Any"), ("argparse", "Namespace"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"),
+}
+# (torch.storage._load_from_bytes is deliberately absent: it unpickles a nested stream with the stock pickle.)
+_BAG_MODULE_ROOTS = ("omegaconf", "pytorch_lightning", "lightning", "lightning_fabric")
 
 
 class _TolerantUnpickler(pickle.Unpickler):
@@ -59,11 +78,10 @@ class _TolerantUnpickler(pickle.Unpickler):
             if name in _SAFE_BUILTINS:
                 return super().find_class(module, name)
             raise pickle.UnpicklingError(f"checkpoint names builtins.{name}: refused")
-        if root in _SAFE_MODULE_ROOTS:
-            try:
-                return super().find_class(module, name)
-            except (ImportError, AttributeError):
-                return type(name, (_Bag,), {"__module__": module})
+        if (module, name) in _SAFE_GLOBALS or (module == "torch" and name in _TORCH_STORAGES):
+            return super().find_class(module, name)
+        if module == "torch" and isinstance(getattr(torch, name, None), torch.dtype):
+            return getattr(torch, name)                  # torch.float32 ... pickle as the global torch.<name>
         raise pickle.UnpicklingError(f"checkpoint names {module}.{name}: refused (not a tensor / container / config class)")
 
 
@@ -83,13 +101,18 @@ class _tolerant_pickle:
 def tolerant_torch_load(path: str) -> Dict[str, Any]:
     """``torch.load(path, map_location='cpu')`` for the reference's checkpoints without executing what they name:
     first torch's own ``weights_only`` loader (pure tensor files: the SD-1.5 first-conv file, official SD checkpoints);
-    files that also pickle OmegaConf nodes (``config_dict`` of instancediffusion_sd15.pth) fall back to an allow-listing
-    unpickler (``_TolerantUnpickler``) that turns the OmegaConf classes into attribute bags and refuses every global
-    outside torch / containers / numpy."""
+    a file that loader REFUSES because it also pickles non-tensor classes (the OmegaConf ``config_dict`` of
+    instancediffusion_sd15.pth, pytorch_lightning callbacks) goes through ``_TolerantUnpickler``, which resolves an exact
+    allow-list of (module, name) globals, turns the config / callback classes into inert attribute bags and refuses every
+    other global.  I/O errors and corrupt files are NOT retried: only the strict loader's refusal of a global is."""
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle)
+    except pickle.UnpicklingError as strict_refusal:
+        try:
+            return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle)
+        except pickle.UnpicklingError as e:
+            raise pickle.UnpicklingError(f"{e} (torch's weights_only loader had refused the file: "
+                                         f"{str(strict_refusal).splitlines()[0]})") from strict_refusal
 
 
 def plain_config(obj: Any) -> Any:

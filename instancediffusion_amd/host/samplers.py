@@ -9,8 +9,10 @@ constructor / ``sample()`` API, same schedule, same update rule and quirks, diff
   * everything step-invariant lives in ``engine.Cond`` objects built once per ``sample()`` call;
   * latents, eps history and the PLMS/CFG arithmetic stay on the GPU in fp32 (fused kernels);
   * with ``torch.distributed`` initialised (one process per GPU, RCCL), MIS phase 1 is sharded over
-    (instance, image) work units, the merge (plms_instance.py:135) is ONE all-reduce of the per-rank partial sums
-    (64 KiB per image), and phase 2 is sharded over images.
+    (instance, image) work units, the instance latents are recombined by ONE all-reduce of the disjoint
+    [instance][image] latent stack (a gather: every element has exactly one non-zero contributor) and merged by the
+    same ``idf_mis_merge`` call as on one rank -- outputs are bit-identical at every world size -- and phase 2 is
+    sharded over images.
 """
 from __future__ import annotations
 
@@ -20,6 +22,13 @@ import numpy as np
 import torch
 
 from .diffusion import make_ddim_timesteps
+
+
+def guided_uc_shared(uc: torch.Tensor) -> bool:
+    """Are all rows of the unconditional context the same tensor (stride-0 broadcast, or equal values)?"""
+    if uc.shape[0] <= 1:
+        return False
+    return uc.stride(0) == 0 or bool((uc[1:] == uc[:1]).all())
 
 
 class _PLMSBase(object):
@@ -218,13 +227,17 @@ class PLMSSamplerInst(_PLMSBase):
         # into the engine's static slot.
         need_j = [sorted({b for (jj, b) in units if jj == j} | (set(mine) if j == 0 else set())) for j in range(n_all)]
         need_u = sorted({b for (_, b) in units} | set(mine))
+        # identical unconditional rows (one negative prompt broadcast over the batch, inference.py:303): build that
+        # conditioning ONCE and let every image gather the same bank row -- with `instance` ownership need_u is all B
+        # images of the global batch, and per-rank setup work must not grow with the world size
+        uc_shared = bool(guided_uc_shared(uc)) if (uc is not None and len(need_u) > 1) else False
         row_of: Dict[tuple, int] = {}
         off = 0
         for j in range(n_all):
             for k, b in enumerate(need_j[j]):
                 row_of[(j, b)] = off + k
             off += len(need_j[j])
-        row_unc = {b: off + k for k, b in enumerate(need_u)}
+        row_unc = {b: off + (0 if uc_shared else k) for k, b in enumerate(need_u)}
 
         def take(v, imgs):
             if not torch.is_tensor(v) or v.dim() == 0 or v.shape[0] != B or len(imgs) == B:
@@ -248,7 +261,7 @@ class PLMSSamplerInst(_PLMSBase):
             return d
 
         conds = [self._cond(local(input_all[j], need_j[j])) for j in range(n_all) if need_j[j]]
-        cond_u = self._uncond(take(uc, need_u)) if (guided and need_u) else None
+        cond_u = self._uncond(take(uc, need_u[:1] if uc_shared else need_u)) if (guided and need_u) else None
         parts = conds + ([cond_u] if cond_u is not None else [])
         bank = type(parts[0]).cat(parts) if parts else None
 
@@ -320,25 +333,22 @@ class PLMSSamplerInst(_PLMSBase):
                 eps_units[u] = [e[k] for e in old]
 
         # ---------------- merge (plms_instance.py:128-135) ------------------------------------------------------
+        # The SAME arithmetic at every world size: the N+1 unit latents of every image are laid out in the fixed order
+        # [instance][image] and idf_mis_merge reduces them (mean, or crop-and-paste) -- a rank fills in the units it ran,
+        # zeros elsewhere, and ONE all-reduce (RCCL) of that stack recombines the instance latents: the supports are
+        # disjoint, x + 0 is exact, so the sum IS a gather and the merged latent is bit-identical to the 1-rank result.
+        # With `image` ownership a rank holds every unit of the images it continues in phase 2: nothing to exchange.
+        lat = torch.zeros((n_all, B) + tuple(shape[1:]), device=dev, dtype=torch.float32)
+        for (j, b), xv in x_units.items():
+            lat[j, b] = xv
+        if dist is not None and mode != "image":
+            dist.all_reduce(lat)                                               # the ONE hot-path collective
         if self.crop_and_paste_latents:
-            lat = torch.zeros((n_all, B) + tuple(shape[1:]), device=dev, dtype=torch.float32)
-            for (j, b), xv in x_units.items():
-                lat[j, b] = xv
-            if dist is not None:
-                dist.all_reduce(lat)                                           # disjoint supports: sum == gather
             boxes = torch.tensor([[int(v * latent_size) for v in inp["grounding_input"]["boxes"][0][0].tolist()]
                                   for inp in input_all[1:]], dtype=torch.int32, device=dev).reshape(-1, 4)
             merged = ops.mis_merge(lat, boxes, ops.empty(tuple(shape), torch.float32), 1)
         else:
-            if dist is None:
-                lat = torch.stack([torch.stack([x_units[(j, b)] for b in range(B)]) for j in range(n_all)])
-                merged = ops.mis_merge(lat.contiguous(), None, ops.empty(tuple(shape), torch.float32), 0)
-            else:
-                part = torch.zeros(tuple(shape), device=dev, dtype=torch.float32)
-                for (j, b), xv in x_units.items():
-                    part[b] += xv
-                dist.all_reduce(part)                                          # the ONE hot-path collective (RCCL)
-                merged = part / float(n_all)
+            merged = ops.mis_merge(lat, None, ops.empty(tuple(shape), torch.float32), 0)
 
         # ---------------- phase 2: shared trajectory, one per image, sharded over images (:138-156) -------------
         out = torch.zeros(tuple(shape), device=dev, dtype=torch.float32)

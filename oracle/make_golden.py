@@ -196,6 +196,63 @@ def gen_case(tag: str, cfg_name: str, variant: str, latent: int, n_boxes: int, b
     return schema
 
 
+@torch.no_grad()
+def gen_full_s50(tag="full_box_s50", S=50, mis=0.36, n_inst=8, alpha_type=(0.8, 0.0, 0.2)):
+    """The BASELINE headline trajectory on the headline model: the UNMODIFIED reference ``PLMSSamplerInst``
+    (plms_instance.py:59-158) driving the full 1.228 B-parameter UNet, B=1, 64x64 latent, S=50 (inference.py:64),
+    N=8 boxes, mis 0.36 (mis_step 18), alpha_type [0.8, 0, 0.2] with the first-conv swap at step 40, guidance 7.5.
+    406 UNet forwards on CPU fp32.  Besides the final latent, the latent entering selected ``p_sample_plms`` calls is
+    kept (call 162 = the merged latent, call 162+7, call 162+22 = first step with alpha 0) so a GPU mismatch can be
+    located in the trajectory."""
+    print(f"[golden] {tag}: full model S={S} N={n_inst} mis={mis}", flush=True)
+    import time
+    cfg = load_cfg("test_box.yaml", "full")
+    model, gi, diffusion, schema, synth = build(cfg)
+    from ldm.models.diffusion.plms_instance import PLMSSamplerInst
+    g = torch.Generator().manual_seed(1234)
+    bx = synth.random_boxes(n_inst, g)
+    gb = synth.make_grounding_batch(1, bx, g)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    context = torch.randn(1, 77, 768, generator=g)
+    uc = torch.randn(1, 77, 768, generator=g)
+    grounding = gi.prepare(gb)
+    patch_first_conv(model, synth.synth_first_conv_sd())
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=list(alpha_type)),
+                              set_alpha_scale=ref_set_alpha_scale, mis=mis)
+    inputs = [dict(x=x.clone(), timesteps=None, context=context, grounding_input=grounding)]
+    for i in range(n_inst):
+        ctx_i = torch.randn(1, 77, 768, generator=g)
+        inputs.append(dict(x=x.clone(), timesteps=None, context=ctx_i, grounding_input=gi.prepare(synth.instance_batch(gb, i))))
+    mis_step = int(S * mis)
+    n_phase1 = (n_inst + 1) * mis_step
+    keep = {n_phase1: "merged", n_phase1 + 7: "phase2_7", n_phase1 + (int(alpha_type[0] * S) - mis_step): "alpha0_first"}
+    for j in range(n_inst + 1):
+        keep[j * mis_step + mis_step - 1] = f"traj{j}_last_in"          # latent entering the last phase-1 step of input j
+    marks = {}
+    calls = [0]
+    t0 = time.time()
+    inner = sampler.p_sample_plms
+
+    def traced(input, *a, **k):
+        if calls[0] in keep:
+            marks[keep[calls[0]]] = input["x"].clone()
+        calls[0] += 1
+        if calls[0] % 10 == 0:
+            print(f"   call {calls[0]}  {time.time() - t0:.0f}s", flush=True)
+        return inner(input, *a, **k)
+    sampler.p_sample_plms = traced
+    out = dict(meta=dict(tag=tag, cfg="test_box.yaml", variant="full", alpha_type=list(alpha_type), latent=64,
+                         n_boxes=n_inst, batch=1, boxes="rand", with_scribbles=False, with_polygons=False, with_segs=False,
+                         S=S, mis=mis, n_inst=n_inst, seg_size=512, x_fp=fp(x), ctx_fp=fp(context), calls=None))
+    out["mis"] = sampler.sample(S=S, shape=tuple(x.shape), input=inputs, uc=uc, guidance_scale=7.5).clone()
+    out["meta"]["calls"] = calls[0]
+    out["marks"] = marks
+    out["plms_timesteps"] = [int(v) for v in sampler.ddim_timesteps]
+    os.chdir(REF)
+    torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
+    print(f"[golden] {tag}: {calls[0]} sampler calls, {time.time() - t0:.0f}s, final std {float(out['mis'].std()):.4f}")
+
+
 # reduced VAE for fast tests: 64 base channels, 3 levels (x4 upsampling), the same block structure (mid attention incl.)
 VAE_VARIANTS = {
     "full": {},
@@ -540,6 +597,8 @@ def main():
         # BASELINE headline trajectory shape (inference.py:64 steps=50, N=8 instances, mis 0.36) on the reduced variants
         gen_case("tiny_box_s50", "test_box.yaml", "tiny", 16, 8, 1, alpha_type=(1, 0, 0), S=50, mis=0.36, n_inst=8)
         gen_case("mid_box_s50", "test_box.yaml", "mid", 16, 8, 1, alpha_type=(0.8, 0.0, 0.2), S=50, mis=0.36, n_inst=8)
+    if args.only in ("full_s50",):          # 406 full-model forwards on CPU (~20 min on 8 cores): not part of "all"
+        gen_full_s50()
     if args.only in ("all", "c5"):
         # C5 (point / scribble conditioning): forwards + S=5 PLMS / MIS trajectories
         gen_case("tiny_point_s5", "test_point.yaml", "tiny", 16, 3, 1, alpha_type=(1, 0, 0))

@@ -15,7 +15,13 @@ import torch.nn.functional as F
 
 
 class EmulOps:
-    def __init__(self, dtype=torch.bfloat16):
+    def __init__(self, dtype=torch.bfloat16, batch_invariant=False):
+        # batch_invariant: make every op's result for one batch row independent of which other rows share the call, the
+        # property the HIP kernels have per launch configuration.  torch's CPU kernels do not have it for free (M < 64
+        # matmuls take a gemv path with another summation order, batch-1 convolutions another algorithm), so matmuls
+        # run in fixed 256-row blocks (the last one zero-padded) and convolutions sample by sample.  Used by the
+        # world-size tests, which require W-rank output == 1-rank output bit for bit.
+        self.batch_invariant = batch_invariant
         self.dtype = dtype
         self.device = torch.device("cpu")
         self.calls = {}
@@ -40,7 +46,19 @@ class EmulOps:
         self._count("gemm")
         assert a.dtype == self.dtype and w.dtype == self.dtype
         assert a.shape[-1] % 64 == 0, "K % 64"
-        acc = torch.matmul(a.float(), w.float().transpose(-1, -2))
+        af32 = a.float()
+        if self.batch_invariant:                       # fixed 256-row blocks (the last one zero-padded), see __init__
+            M, BLK = af32.shape[-2], 256
+            wt = w.float().transpose(-1, -2)
+            blocks = []
+            for m0 in range(0, M, BLK):
+                blk = af32[..., m0:m0 + BLK, :]
+                if blk.shape[-2] < BLK:
+                    blk = torch.cat([blk, torch.zeros(*blk.shape[:-2], BLK - blk.shape[-2], blk.shape[-1])], -2)
+                blocks.append(torch.matmul(blk, wt)[..., :min(BLK, M - m0), :])
+            acc = torch.cat(blocks, -2)
+        else:
+            acc = torch.matmul(af32, w.float().transpose(-1, -2))
         if ln_row is not None:                         # include/idf.h IDF_EPI_LN_ROW: rstd_m * (acc - mu_m c_n) (+ d as bias)
             st, c = ln_row
             assert bias is not None
@@ -90,7 +108,10 @@ class EmulOps:
         xi = x.float().permute(0, 3, 1, 2)
         if upsample:
             xi = F.interpolate(xi, scale_factor=2, mode="nearest")
-        y = F.conv2d(xi, wt, None, stride=stride, padding=1)
+        if self.batch_invariant:
+            y = torch.cat([F.conv2d(xi[i:i + 1], wt, None, stride=stride, padding=1) for i in range(B)], 0)
+        else:
+            y = F.conv2d(xi, wt, None, stride=stride, padding=1)
         if bias is not None:
             y = y + bias.view(1, -1, 1, 1)
         if rowbias is not None:
@@ -105,7 +126,11 @@ class EmulOps:
 
     def conv_in(self, x_nchw, w, bias, out):
         self._count("conv_in")
-        out.copy_(F.conv2d(x_nchw, w, bias, padding=1).permute(0, 2, 3, 1))
+        if self.batch_invariant:
+            y = torch.cat([F.conv2d(x_nchw[i:i + 1], w, bias, padding=1) for i in range(x_nchw.shape[0])], 0)
+        else:
+            y = F.conv2d(x_nchw, w, bias, padding=1)
+        out.copy_(y.permute(0, 2, 3, 1))
         return out
 
     def attention(self, q, k0, vt0, n0, out, heads, *, k1=None, vt1=None, n1=0, qbits=None, kbits0=None, kbits1=None):

@@ -159,6 +159,65 @@ def test_checkpoint_loading_refuses_foreign_globals_and_targets(tmp_path):
     torch.save(dict(model={}, payload=Evil()), path)
     with pytest.raises(pickle.UnpicklingError):
         ck.tolerant_torch_load(path)
+    # an allow-listed module ROOT is not enough: callables inside torch / numpy that execute their argument
+    # must be refused, and refused BEFORE anything runs
+    import numpy.testing._private.utils as npu
+    import torch.utils.collect_env as ce
+    marker = tmp_path / "ran"
+
+    class RunString:
+        def __reduce__(self):
+            return (npu.runstring, (f"open({str(marker)!r}, 'w').write('x')", {}))
+
+    class CollectEnv:
+        def __reduce__(self):
+            return (ce.run, (f"touch {marker}",))
+
+    class HubLoad:
+        def __reduce__(self):
+            return (torch.hub.load, ("x/y", "z"))
+    for k, payload in enumerate((RunString(), CollectEnv(), HubLoad())):
+        path_k = str(tmp_path / f"evil{k}.pth")
+        torch.save(dict(model={}, payload=payload), path_k)
+        with pytest.raises(pickle.UnpicklingError, match="refused"):
+            ck.tolerant_torch_load(path_k)
+        with open(path_k, "wb") as f:                       # a bare pickle (no zip container), as in the advisor's PoC
+            pickle.dump(dict(payload=payload), f)
+        with pytest.raises(Exception):
+            ck.tolerant_torch_load(path_k)
+        assert not marker.exists(), "the payload must not have run"
+    # what a real checkpoint holds still loads: tensors of several dtypes, parameters, numpy arrays / scalars, an
+    # argparse.Namespace, an OrderedDict, and pytorch_lightning callback objects as inert bags
+    import argparse
+    import collections
+    import sys
+    import types
+    import numpy as np
+    pl = types.ModuleType("pytorch_lightning")
+    plc = types.ModuleType("pytorch_lightning.callbacks")
+
+    class ModelCheckpoint:
+        def __init__(self):
+            self.best = 0.5
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = "pytorch_lightning.callbacks", "ModelCheckpoint"
+    plc.ModelCheckpoint = ModelCheckpoint
+    sys.modules.update({"pytorch_lightning": pl, "pytorch_lightning.callbacks": plc})
+    try:
+        good = dict(state_dict=collections.OrderedDict(a=torch.ones(2, dtype=torch.float16), b=torch.arange(3)),
+                    p=torch.nn.Parameter(torch.zeros(1)), arr=np.arange(4.0), sc=np.float32(2.5),
+                    args=argparse.Namespace(lr=0.1), callbacks={"ckpt": ModelCheckpoint()}, dt=torch.bfloat16)
+        path_g = str(tmp_path / "good.pth")
+        torch.save(good, path_g)
+    finally:
+        sys.modules.pop("pytorch_lightning"), sys.modules.pop("pytorch_lightning.callbacks")
+    back = ck.tolerant_torch_load(path_g)
+    assert torch.equal(back["state_dict"]["a"], good["state_dict"]["a"]) and back["args"].lr == 0.1
+    assert float(back["sc"]) == 2.5 and back["arr"].tolist() == [0.0, 1.0, 2.0, 3.0] and back["dt"] == torch.bfloat16
+    assert type(back["callbacks"]["ckpt"]).__name__ == "ModelCheckpoint" and back["callbacks"]["ckpt"].best == 0.5
+    assert isinstance(back["callbacks"]["ckpt"], ck._Bag)
+    # a missing file is an I/O error, not something to retry with the weaker unpickler
+    with pytest.raises(FileNotFoundError):
+        ck.tolerant_torch_load(str(tmp_path / "nope.pth"))
     with pytest.raises(ValueError):
         ck.check_target_namespace(dict(model=dict(target="os.system", params={})))
     ck.check_target_namespace(dict(model=dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel")))

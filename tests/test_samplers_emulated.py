@@ -20,13 +20,13 @@ from tests.emul_ops import EmulOps
 from tests.test_engine_emulated import build_model
 
 
-def setup(tag, dtype=torch.float32):
+def setup(tag, dtype=torch.float32, batch_invariant=False):
     gold = cases.load_golden(tag)
     meta = gold["meta"]
     cfg = cases.cfg_for(meta["cfg"], meta["variant"])
     inp = cases.build_inputs(meta)
     model = build_model(cfg)
-    model._engine = UNetEngine(model, ops=EmulOps(dtype), use_graphs=False)
+    model._engine = UNetEngine(model, ops=EmulOps(dtype, batch_invariant=batch_invariant), use_graphs=False)
     model.first_conv_sd_override = synth.synth_first_conv_sd()
     gi = GroundingNetInput()
     model.grounding_tokenizer_input = gi
@@ -89,12 +89,25 @@ def test_mis_serial_quirk_and_crop_paste_vs_oracle():
     assert cases.rel_rms(out, want) < 5e-3
 
 
+WORKER_THREADS = 2           # torch's CPU kernels reduce in a thread-count-dependent order: compare like with like
+
+
+def _single_process_run(sampler, meta, inp, gi):
+    n = torch.get_num_threads()
+    torch.set_num_threads(WORKER_THREADS)
+    try:
+        return sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
+                              guidance_scale=7.5)
+    finally:
+        torch.set_num_threads(n)
+
+
 def _dist_worker(rank, world, port, q, sharding="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    torch.set_num_threads(2)
+    torch.set_num_threads(WORKER_THREADS)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    gold, meta, inp, model, gi, diffusion = setup("tiny_box")
+    gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
                               set_alpha_scale=set_alpha_scale, mis=meta["mis"], unit_sharding=sharding)
     out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
@@ -127,10 +140,13 @@ def test_mis_sharded_world2_gloo(sharding):
     # work really was split: count the batch ROWS that went through the attention op (launches x batch -- the launch count
     # alone does not shrink, a rank just runs narrower forwards).  Each rank must do strictly less than a single process,
     # and together no more than the single process plus the per-rank duplicates of the hoisted first evaluation.
-    gold, meta, inp, model, gi, diffusion = setup("tiny_box")
+    gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
                               set_alpha_scale=set_alpha_scale, mis=meta["mis"])
-    sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"], guidance_scale=7.5)
+    one = _single_process_run(sampler, meta, inp, gi)
+    # the merge runs the same arithmetic at every world size (gathered [instance][image] stack -> idf_mis_merge) and a
+    # row's forward does not depend on which other rows share its batch: the 2-rank result IS the 1-rank result
+    assert torch.equal(one, res[0][1]) and torch.equal(one, res[1][1]), "world 2 must be bit-identical to one process"
     single = sampler.engine.ops.rows["attention"]
     r0, r1 = res[0][2], res[1][2]
     print(f"[sharding={sharding}] attention rows: single process {single}, rank0 {r0}, rank1 {r1}")
@@ -160,10 +176,12 @@ def test_mis_sharded_world3_more_ranks_than_images_gloo():
     for rank, out, n_attn in res:
         assert cases.rel_rms(out, gold["mis"]) < 5e-3, rank
         assert torch.equal(out, res[0][1]), rank
-    gold, meta, inp, model, gi, diffusion = setup("tiny_box")
+    gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
                               set_alpha_scale=set_alpha_scale, mis=meta["mis"])
-    sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"], guidance_scale=7.5)
+    one = _single_process_run(sampler, meta, inp, gi)
+    for rank, out, _ in res:
+        assert torch.equal(one, out), f"rank {rank} of world 3 must be bit-identical to one process"
     single = sampler.engine.ops.rows["attention"]
     rows = [n for _, _, n in res]
     print(f"[world 3, instance] attention rows: single process {single}, per rank {rows}")

@@ -43,6 +43,9 @@ def install_shims():
     registry.register_model = lambda f: f
     timm = types.ModuleType("timm")
     models = types.ModuleType("timm.models")
+    import importlib.machinery
+    for name, m in (("timm", timm), ("timm.models", models), ("timm.models.layers", layers), ("timm.models.registry", registry)):
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)      # transformers probes find_spec("timm")
     sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers,
                         "timm.models.registry": registry})
     torch.hub.load_state_dict_from_url = lambda *a, **k: {"model": {}}
@@ -573,6 +576,78 @@ def gen_ckpt_case(tag="ckpt_tiny"):
         sys.modules.pop("utils.dist", None)
 
 
+# ---- f-3: CLIP text-encoder forward pin (ldm/modules/encoders/modules.py:144-172) --------------------------------------
+# the hub's config.json of openai/clip-vit-large-patch14 (text part), which ``from_pretrained`` would have fetched
+CLIP_HUB_TEXT_CONFIG = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, projection_dim=768,
+                            num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
+                            layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+CLIP_SALT = 21
+
+
+def clip_input_ids():
+    """Two fixed CLIP-BPE-shaped id rows (<|startoftext|> 49406, word ids, <|endoftext|> 49407, padded with 49407 as the
+    openai tokenizer pads): the tokenizer itself cannot run offline (no vocabulary files), the transformer can."""
+    g = torch.Generator().manual_seed(77)
+    ids = torch.full((2, 77), 49407, dtype=torch.long)
+    for r, n in enumerate((9, 40)):
+        ids[r, 0] = 49406
+        ids[r, 1:1 + n] = torch.randint(320, 49000, (n,), generator=g)
+    return ids
+
+
+@torch.no_grad()
+def gen_clip_case(tag="clip_text"):
+    """The UNMODIFIED reference ``FrozenCLIPEmbedder`` (its ``forward`` / ``encode`` / ``freeze`` code paths as written) on
+    key-name-seeded weights and fixed ``input_ids``.  Process-local shims: ``clip`` / ``kornia`` stub modules (imported at the
+    top of encoders/modules.py, unused by this class), ``CLIPTextModel.from_pretrained`` -> construction from the hub's
+    config (no network), ``CLIPTokenizer.from_pretrained`` -> a callable returning the fixed ids."""
+    import importlib
+    import importlib.util
+    import transformers
+    print(f"[golden] {tag}: FrozenCLIPEmbedder forward (transformers {transformers.__version__})", flush=True)
+    ids = clip_input_ids()
+
+    class FixedTokenizer:
+        def __call__(self, text, **kw):
+            assert kw.get("max_length") == 77 and kw.get("padding") == "max_length" and kw.get("truncation") is True
+            return {"input_ids": ids[:len(text)]}
+    stubs = {"clip": types.ModuleType("clip"), "kornia": types.ModuleType("kornia")}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    real_model_fp, real_tok_fp = transformers.CLIPTextModel.from_pretrained, transformers.CLIPTokenizer.from_pretrained
+    transformers.CLIPTextModel.from_pretrained = classmethod(
+        lambda cls, version, *a, **k: cls(transformers.CLIPTextConfig(**CLIP_HUB_TEXT_CONFIG)))
+    transformers.CLIPTokenizer.from_pretrained = classmethod(lambda cls, version, *a, **k: FixedTokenizer())
+    try:
+        mod = importlib.import_module("ldm.modules.encoders.modules")
+        enc = mod.FrozenCLIPEmbedder(device="cpu")
+        spec = importlib.util.spec_from_file_location("idf_synth", os.path.join(REPO, "instancediffusion_amd", "synth.py"))
+        synth = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(synth)
+        schema = {k: tuple(v.shape) for k, v in enc.state_dict().items() if v.is_floating_point()}
+        sd = synth.synth_state_dict(schema, CLIP_SALT)
+        missing = enc.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all("position_ids" in k for k in missing.missing_keys), missing
+        z, pooled = enc.encode(["a", "b"], return_pooler_output=True)
+        z_only = enc(["a", "b"])
+        assert torch.equal(z, z_only)
+        out = dict(meta=dict(tag=tag, salt=CLIP_SALT, transformers=transformers.__version__, hub_config=dict(CLIP_HUB_TEXT_CONFIG),
+                             key_layout=sorted(schema)[:3], n_keys=len(schema)),
+                   input_ids=ids, last_hidden_state=z.clone(), pooler_output=pooled.clone(),
+                   schema={k: list(v) for k, v in schema.items()})
+        torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
+        print(f"[golden] {tag}: z {tuple(z.shape)} std {float(z.std()):.4f}, pooled {tuple(pooled.shape)}; "
+              f"{sum(int(np.prod(v)) for v in schema.values())} parameters")
+    finally:
+        transformers.CLIPTextModel.from_pretrained, transformers.CLIPTokenizer.from_pretrained = real_model_fp, real_tok_fp
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.modules.pop("ldm.modules.encoders.modules", None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -618,6 +693,8 @@ def main():
         gen_input_case()
     if args.only in ("all", "ckpt"):
         gen_ckpt_case()
+    if args.only in ("all", "clip"):
+        gen_clip_case()
     print("done")
 
 

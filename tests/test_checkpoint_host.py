@@ -255,3 +255,52 @@ def test_clip_text_encoder_wrapper_offline():
     if not os.environ.get("IDF_CLIP_PATH"):
         with pytest.raises(RuntimeError, match="vocabulary"):
             enc.encode(["a cat"])
+
+
+def _clip_vs_golden(device):
+    """The wrapper (built from ITS OWN fixed config, weights through ITS load_state_dict key remap) against the
+    last_hidden_state / pooler_output the unmodified reference FrozenCLIPEmbedder produced on the same key-seeded weights
+    and input_ids (tests/golden/clip_text.pt, oracle/make_golden.py --only clip).  The tokenizer is bypassed on both
+    sides: its vocabulary files do not exist offline."""
+    from instancediffusion_amd import synth
+    from ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    from tests import cases
+    gold = cases.load_golden("clip_text")
+    enc = FrozenCLIPEmbedder(device=device)
+    sd = synth.synth_state_dict({k: tuple(v) for k, v in gold["schema"].items()}, gold["meta"]["salt"])
+    # hand the weights over in the OTHER key layout than the golden's, so the remap is what is being tested too
+    nested = any(k.startswith("transformer.text_model.") for k in sd)
+    if nested:
+        other = {"transformer." + k[len("transformer.text_model."):]: v for k, v in sd.items()}
+    else:
+        other = {"transformer.text_model." + k[len("transformer."):]: v for k, v in sd.items()}
+    res = enc.load_state_dict(other, strict=False)
+    assert not res.unexpected_keys and all("position_ids" in k for k in res.missing_keys), res
+    enc = enc.to(device)
+    ids = gold["input_ids"]
+
+    class FixedTokenizer:
+        def __call__(self, text, **kw):
+            return {"input_ids": ids[:len(text)]}
+    enc._tokenizer = FixedTokenizer()
+    z, pooled = enc.encode(["a", "b"], return_pooler_output=True)
+    ez = cases.rel_rms(z.float().cpu(), gold["last_hidden_state"])
+    ep = cases.rel_rms(pooled.float().cpu(), gold["pooler_output"])
+    print(f"[parity] CLIP text encoder wrapper on {device} fp32 vs the reference class: last_hidden_state rel-rms {ez:.2e}, "
+          f"pooler_output {ep:.2e} (tol 1e-5)")
+    assert tuple(z.shape) == (2, 77, 768) and tuple(pooled.shape) == (2, 768)
+    assert float(gold["last_hidden_state"][0].std(0).mean()) > 1e-3, "degenerate golden"
+    assert ez < 1e-5 and ep < 1e-5
+    # pooler_output = the hidden state at the FIRST <|endoftext|> (row 0: position 10, row 1: position 41)
+    assert torch.allclose(pooled[0].cpu(), z[0, 10].cpu(), atol=1e-6) and torch.allclose(pooled[1].cpu(), z[1, 41].cpu(), atol=1e-6)
+
+
+def test_clip_text_encoder_forward_matches_reference_golden():
+    pytest.importorskip("transformers")
+    _clip_vs_golden("cpu")
+
+
+@pytest.mark.gpu
+def test_clip_text_encoder_forward_matches_reference_golden_gpu():
+    pytest.importorskip("transformers")
+    _clip_vs_golden("cuda")

@@ -11,9 +11,9 @@ guidance 7.5, N=8 box instances, Multi-instance Sampler mis=0.36 (=> 406 UNet fo
 [0.8, 0, 0.2].  One "step" = one full sampling of the global image batch.  Default: weak scaling, images_per_gpu x n_gpus
 images per step; ``--images-total K`` fixes the global batch instead (strong scaling, e.g. 8 images on 1 / 2 / 4 / 8 GPUs).
 At n_gpus > 1 the (instance, image) work units of MIS phase 1 are sharded over the ranks by ``--sharding``: "instance"
-(default; owner = (image + instance) mod N: the N+1 trajectories of every image are spread over the GPUs and the merge is
-a real RCCL all-reduce of partial latent sums -- north_star's split) or "image" (owner = image mod N: replicas, the
-all-reduce adds zeros).  Inputs are resident in HBM before the timed region.  VAE decode is outside the path.
+(default; owner = (image + instance) mod N: the N+1 trajectories of every image are spread over the GPUs and ONE RCCL
+all-reduce of the disjoint [instance][image] latent stack -- a gather -- recombines them before the same idf_mis_merge
+call as on one GPU: north_star's split) or "image" (owner = image mod N: replicas, nothing to exchange at the merge).  Inputs are resident in HBM before the timed region.  VAE decode is outside the path.
 
 Prints ONE JSON line on rank 0 with the driver contract fields plus
   "roofline"     -- dominant kernel's achieved TFLOP/s (algorithmic flops / HIP-event duration) vs 2.5 PF bf16 MFMA
@@ -187,7 +187,8 @@ def measure_roofline(engine, batch, fuser_on=True):
                        "gemm_kernel<..,true> + split-K below 8^2)",
             "gemm": "gemm_kernel_big<.., CONV=false> (persistent 256x{320,256}-tile dense GEMM, LDS-DMA staging, in-register "
                     "epilogue; gemm_kernel_dma 128x128 for batched / badly quantised shapes)",
-            "attention": "attn2_kernel<.., LAZY> (64 queries/wave, LDS-DMA K/V^T, lazy rescaling) / attn_kernel for d=80,160"
+            "attention": "attn4_kernel<DT,3,2,1> for d=40 (64 queries/wave, LDS-DMA K / V^T rings, max-free softmax, XCD-aware "
+                         "grid) / attn_kernel for d=80,160 and the 77-key cross-attention"
             }.get(name, name)
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     pmc = pmc_traffic(name, batch)
@@ -198,6 +199,7 @@ def measure_roofline(engine, batch, fuser_on=True):
                 frac=round(achieved / PEAK_MFMA_TF, 4),
                 traffic=None if pmc is None else float(pmc["hbm_bytes_per_launch"]), traffic_unit="bytes/launch",
                 traffic_source=None if pmc is None else pmc.get("source"),
+                traffic_measured_in_this_run=False,      # a table lookup of the committed rocprofv3 --pmc passes (counters cannot be read from inside the process)
                 launches_per_forward=d["calls"], avg_launch_us=round(d["ms"] * 1e3 / d["calls"], 2),
                 algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
                 algorithmic_mbytes_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2), measured_at_batch=batch,
@@ -259,6 +261,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="storage / MFMA input type of the headline run")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the short leg in the other 16-bit type")
     ap.add_argument("--no-strong-leg", action="store_true", help="at n_gpus > 1: skip the short strong-scaling leg (8 images total)")
+    ap.add_argument("--no-ref-batch-leg", action="store_true", help="at 1 GPU: skip the short leg at the reference's own batch (8 images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -354,13 +357,16 @@ def main():
             "ms_per_step": round(main_leg["ms_per_step"], 2), "higher_is_better": True,
             "scaling": "strong" if args.images_total else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            # what torch.distributed itself reports (the driver's SCALE record can check that RCCL saw N ranks)
+            "dist_backend": dist.get_backend() if world > 1 else None,
+            "dist_world_size": dist.get_world_size() if world > 1 else 1,
             "config": {"workload": "C3: SD-1.5 InstanceDiffusion UNet (1.228B params, seeded random weights), 64x64 latent "
                                    "(512x512), 50 PLMS steps, CFG 7.5, N=8 boxes, MIS 0.36, alpha [0.8,0,0.2]",
                        "images_per_gpu": None if args.images_total else args.images_per_gpu,
                        "global_images_per_step": n_images, "unet_forwards_per_image": nf,
                        "sharding": args.sharding if world > 1 else "none (1 GPU)",
-                       "parallelism": f"MIS (instance, image) units sharded x{world} [{args.sharding}], one RCCL all-reduce at "
-                                      f"the merge; phase 2 sharded over images x{world}"},
+                       "parallelism": f"MIS (instance, image) units sharded x{world} [{args.sharding}], one RCCL all-reduce (gather "
+                                      f"of the instance latents) at the merge; phase 2 sharded over images x{world}"},
             # reference-algorithmic work: every forward the reference runs (406 per image) at its own 1227.3 GFLOP
             "whole_step_algorithmic_tflops_per_gpu": round(value * nf * GFLOP_PER_FWD / 1e3 / world, 1),
             "whole_step_frac_of_mfma_peak": round(value * nf * GFLOP_PER_FWD / 1e3 / world / PEAK_MFMA_TF, 4),
@@ -394,6 +400,13 @@ def main():
             line["strong_scaling_leg"] = dict(global_images=k, value=round(leg["value"], 4), unit="img/s", steps=1, warmup=1,
                                               ms_per_step=round(leg["ms_per_step"], 2), sharding=args.sharding,
                                               forward_rows_per_image=round((leg["rows_on"] + leg["rows_off"]) / k, 1))
+    if world == 1 and not args.no_ref_batch_leg and not args.images_total and args.images_per_gpu != 8:
+        # the reference's own batch: num_images = 8 per prompt (inference.py) on one GPU -- phase 1 runs
+        # 72 units as 2 x 64-row + 1 x 16-row forwards per step, phase 2 16-row forwards
+        leg = run_leg(args.dtype, 8, 1, 1, args.sharding)
+        line["reference_batch_leg"] = dict(global_images=8, value=round(leg["value"], 4), unit="img/s", steps=1, warmup=1,
+                                           ms_per_step=round(leg["ms_per_step"], 2),
+                                           forward_rows_per_image=round((leg["rows_on"] + leg["rows_off"]) / 8, 1))
     if not args.no_alt_dtype:
         alt = "fp16" if args.dtype == "bf16" else "bf16"
         leg = run_leg(alt, n_images, 1, 1, args.sharding)

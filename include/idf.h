@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IDF_ABI_VERSION 2
+#define IDF_ABI_VERSION 3
 
 enum { IDF_BF16 = 0, IDF_F16 = 1 };                 /* 16-bit storage / MFMA input type */
 enum { IDF_E_ARG = -1, IDF_E_ALIGN = -2, IDF_E_UNSUPPORTED = -3 };
@@ -52,25 +52,16 @@ int idf_abi_version(void);
 const char* idf_build_info(void);
 
 /* Kernel-selection knobs (process-global, for A/B measurement and for tests that must hit one specific kernel;
- * results are identical up to fp32 summation order).  Returns the previous value, or IDF_E_ARG for an unknown knob.
- *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256}-tile GEMM/conv kernel, 1 = automatic
- *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default.
- *   IDF_TUNE_GEMM_GEOM: geometry / fill schedule of that kernel (env IDF_GEMM_GEOM): 0 = one 8-wave workgroup per CU on
- *   256-row tiles (64-deep K-tiles, 2 LDS stages); waves 4-7 enqueue the next K-tile's LDS-DMA pieces from the middle of
- *   their MFMAs (default); 1 = two independent 4-wave workgroups per CU on 128-row tiles (32-deep K-tiles, 3 / 2 stages);
- *   2 = ping-pong: the two waves of a SIMD in opposite load / compute roles on 32-deep half-tiles, 4 stages;
- *   3 / 4 / 5 = geometry 0 with waves 4-7 filling from the end / the middle of their K-tile / every wave spreading its
- *   pieces between its MFMAs; 6 = geometry 0 with four 32-deep stages for the 256-wide tiles.
- *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; otherwise, when the shape qualifies, the
- *   64-queries-per-wave LDS-DMA kernel: 1 = classic online softmax, 2 = software-pipelined form (softmax of one query
- *   group beside the MFMAs of the other), 3 = lazy rescaling, 4 = pipelined + lazy (d in {24,40,56}, n0 % 8 == n1 % 8 == 0); 5 = variant 4 (attention4.hip: max-free
- *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid),
- *   6 = variant 4 with the plain block order (A/B of the XCD mapping), 7 / 8 = variant 4 with V^T fetched two tiles ahead;
- *   9..14 = variant 5 (attention5.hip: variant 4 as one 8-wave workgroup per 512 queries whose two waves per SIMD alternate
- *   between a matrix phase and a scalar phase): (value - 9) & 1 = plain block order instead of the XCD-aware one,
- *   (value - 9) >> 1 = s_setprio 1 in no phase / the matrix phases / the scalar phases.
- *   Initial value: env IDF_ATTN2 or default (5). */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_GEOM = 2 };
+ * results are identical up to fp32 summation order).  Returns the previous value, or IDF_E_ARG for an unknown knob / value.
+ *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256,128}-tile GEMM/conv kernel, 1 = automatic
+ *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default (1).
+ *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; 1 = when the shape qualifies
+ *   (d in {24,40,56}, n0 % 8 == n1 % 8 == 0, no mask) the 64-queries-per-wave LDS-DMA kernel (attention4.hip: max-free
+ *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid);
+ *   2 = the same with the plain block order (A/B of the XCD mapping).  Initial value: env IDF_ATTN2 or the default (1).
+ * (ABI 2 also exposed the kernel variants that were measured slower -- GEMM geometries 1..6, attention modes 1..14; they
+ * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.) */
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1 };
@@ -103,6 +94,14 @@ typedef struct {
    * kernels -- with eps = ln_eps; K must be the whole LayerNorm row (K % 8 == 0, K <= 1536), batch 1.  ln_stats_out
    * (f32 [M][2], or NULL) receives them, e.g. for the LN_COL projection of the same matrix that follows. */
   float ln_eps; float* ln_stats_out;
+  /* Fused q | k | v projection (attention.py:168-172 -- to_q, to_k, to_v read the same LayerNorm output): with vt_out != NULL
+   * the output columns n >= vt_col0 are stored TRANSPOSED, vt_out[(n - vt_col0) * ld_vt + m] (16-bit; ld_vt >= M, % 8 == 0)
+   * -- the V^T[channel][token] image idf_attention consumes -- and `out` holds the first vt_col0 columns only.  Epilogue:
+   * BIAS and / or LN_ROW only (LN_ROW's beta term of a transposed column is bias[n] as for the others), batch 1, no
+   * out_stats; self-normalising LN_ROW additionally needs ln_stats_out.  One launch of the persistent kernel when
+   * N % 320 == vt_col0 % 320 == 0 and M % 16 == 0 (its transposed tiles run the same K loop with the MFMA operands swapped);
+   * any other shape runs as the two GEMMs this replaces. */
+  void* vt_out; int ld_vt; int vt_col0;
 } idf_gemm_args;
 int idf_gemm(const idf_gemm_args* a, void* stream);
 

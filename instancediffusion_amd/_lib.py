@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDF_LIB_PATH", os.path.join(_HERE, "libidf_gfx950.so"))   # override: A/B builds only
 
 IDF_BF16, IDF_F16 = 0, 1
+IDF_STAT_GEMM_BIG_LAUNCHES, IDF_STAT_ATTN2_LAUNCHES = 0, 1        # idf_get_stat
+IDF_TUNE_GEMM_BIG, IDF_TUNE_ATTN2 = 0, 1                         # idf_set_tuning
 EPI_LN_ROW, EPI_LN_COL = 512, 1024
 EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \
     1, 2, 4, 8, 16, 32, 64, 128, 256
@@ -28,7 +30,8 @@ class GemmArgs(C.Structure):
                 ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll),
                 ("ln_stats", vp), ("stride_ln_stats", ll), ("ln_c", vp), ("ln_d", vp),
                 ("out_stats", vp), ("out_stats_eps", cf),
-                ("ln_eps", cf), ("ln_stats_out", vp)]
+                ("ln_eps", cf), ("ln_stats_out", vp),
+                ("vt_out", vp), ("ld_vt", ci), ("vt_col0", ci)]
 
 
 class ConvArgs(C.Structure):
@@ -98,7 +101,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.idf_abi_version() != 2:
+    if lib.idf_abi_version() != 3:
         raise RuntimeError("libidf_gfx950.so ABI version mismatch")
     _lib = lib
     return lib

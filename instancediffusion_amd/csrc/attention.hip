@@ -47,11 +47,27 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  // XCD-aware block order (round 3): hardware block L (x fastest) runs on XCD L % 8 and every XCD has its own L2.  In
+  // launch order the query blocks of one (batch, head) land on 8 different XCDs and each of them fetches that head's K / V^T
+  // (PMC at batch 64, d = 80: 6.1x the algorithmic fetch bytes).  Give every XCD a CONTIGUOUS range of the logical
+  // (b, h, query block) list instead: the blocks sharing a K / V^T slice share an L2.
+  int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * (int)gridDim.z;
+    if ((total & 7) == 0) {
+      int L = bx + gx * (h + gy * b);
+      L = (L & 7) * (total >> 3) + (L >> 3);
+      bx = L % gx;
+      const int r = L / gx;
+      h = r % gy;
+      b = r / gy;
+    }
+  }
   const int d = p.d;
   const int dch = d >> 3;                            // 16-B chunks per K row
   const int nqb = (p.nq + 127) / 128;
-  const int qb0 = RES ? (int)blockIdx.x * qpw : (int)blockIdx.x;
+  const int qb0 = RES ? bx * qpw : bx;
   const int qb1 = RES ? min(nqb, qb0 + qpw) : qb0 + 1;
 
   // zero LDS once: pad columns of K (d..16*NKS) and pad rows of V^T (d..32*NMT) must stay finite zeros
@@ -371,6 +387,8 @@ int launch_attn(const AttnParams& p, int B, hipStream_t s) {
 
 }  // namespace
 
+std::atomic<long long> idf_stat_attn2_launches{0};
+
 int g_attn2_mode = -2;
 int idf_attn2_mode() {
   if (g_attn2_mode == -2) { const char* e = getenv("IDF_ATTN2"); g_attn2_mode = e ? atoi(e) : IDF_ATTN2_DEFAULT; }
@@ -406,17 +424,9 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
     p.kbits[1] = (const unsigned*)(a->n1 > 0 ? a->kbits1 : a->kbits0); p.sKb[1] = a->n1 > 0 ? a->strideKb1 : a->strideKb0;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (!a->qbits && idf_attn2_mode() >= 9) {
-    const int rc = idf_launch_attn5(p, a->B, a->dtype, s);
-    if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }
-  }
-  if (!a->qbits && idf_attn2_mode() >= 5) {
+  if (!a->qbits && idf_attn2_mode() > 0) {
     const int rc = idf_launch_attn4(p, a->B, a->dtype, s);
     if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }
-  }
-  if (!a->qbits && idf_attn2_mode() > 0) {
-    const int rc = idf_launch_attn2(p, a->B, a->dtype, s);
-    if (rc != IDF_ATTN2_UNSUPPORTED) return rc;
   }
   if (a->dtype == IDF_BF16) return launch_attn<IDF_BF16>(p, a->B, s);
   if (a->dtype == IDF_F16) return launch_attn<IDF_F16>(p, a->B, s);

@@ -479,26 +479,44 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   }
 
   // ---- normalise and store.  o[g][mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31 of group g.
-  // row e = D of O^T holds the denominator: tile D/32, register 4*((D%32)/8) of the hi = 0 lanes
+  // row e = D of O^T holds the denominator: tile D/32, register 4*((D%32)/8) of the hi = 0 lanes.
+  // A lane owns ONE query row in 8-byte pieces: stored directly that is DCH 8-B stores per lane at a 2*ldo-byte lane
+  // stride -- store-issue-bound, and every 8-B piece is a partial 32-B sector (PMC: 4.6x the algorithmic write bytes,
+  // profiles/r02_rocprof/pmc_traffic_b64.json).  The K / V^T rings are dead here (every wave passed the last tile's
+  // barrier), so each wave transposes its 64 x D block through its own LDS slice and writes 16 B per lane with consecutive
+  // lanes on consecutive chunks of a row: a wave store instruction covers whole 2*D-byte row segments.
   constexpr int sel = (D & 31) >> 3;
+  static_assert(4 * 64 * D <= 3 * KSZ + VST * VSZ, "the O staging block must fit the K / V^T rings");
+  unsigned short* const ow = smem + wave * (64 * D);       // wave-private [64 queries][D]
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float lv = o[g][NMT - 1][4 * sel];
     const float l_tot = __shfl(lv, l31, 64);               // broadcast from the hi = 0 lane of this query
     const float inv = 1.0f / l_tot;
-    if (qrow[g] < p.nq) {
-      unsigned short* op = p.out + (size_t)b * p.sO + (size_t)qrow[g] * p.ldo + h * D;
+    unsigned short* orow = ow + (g * 32 + l31) * D;
 #pragma unroll
-      for (int mt = 0; mt < NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int e = mt * 32 + 8 * qd + 4 * hi;
-          if (e < D) {
-            u32x2 pkd = {pack2<DT>(o[g][mt][4 * qd] * inv, o[g][mt][4 * qd + 1] * inv),
-                         pack2<DT>(o[g][mt][4 * qd + 2] * inv, o[g][mt][4 * qd + 3] * inv)};
-            *reinterpret_cast<u32x2*>(op + e) = pkd;
-          }
+      for (int qd = 0; qd < 4; ++qd) {
+        const int e = mt * 32 + 8 * qd + 4 * hi;
+        if (e < D) {
+          u32x2 pkd = {pack2<DT>(o[g][mt][4 * qd] * inv, o[g][mt][4 * qd + 1] * inv),
+                       pack2<DT>(o[g][mt][4 * qd + 2] * inv, o[g][mt][4 * qd + 3] * inv)};
+          *reinterpret_cast<u32x2*>(orow + e) = pkd;
         }
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, in order, before its reads
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int q0 = qb * 256 + wave * 64;
+    unsigned short* const obase = p.out + (size_t)b * p.sO + h * D;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      const int c = lane + 64 * j;                          // 16-B chunk of the block, row-major: byte offset 16 c
+      const int row = c / DCH, col = c - row * DCH;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ow + c * 8);
+      if (q0 + row < p.nq) *reinterpret_cast<u32x4*>(obase + (size_t)(q0 + row) * p.ldo + col * 8) = v;
     }
   }
 }
@@ -509,9 +527,7 @@ int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
   dim3 grid(nqb * p.H * B), block(256);
 #define IDF_ATTN4_CASE(KS, MT) \
   if (p.d == 8 * (2 * KS - 1)) { \
-    const int mode = idf_attn2_mode(); \
-    if (mode >= 7) hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 2>), grid, block, 0, s, p, nqb, mode == 8 ? 0 : 1); \
-    else hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1>), grid, block, 0, s, p, nqb, mode == 6 ? 0 : 1); \
+    hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1>), grid, block, 0, s, p, nqb, idf_attn2_mode() == 2 ? 0 : 1); \
     return idf_launch_status(); }
   IDF_ATTN4_CASE(2, 1)    // d = 24
   IDF_ATTN4_CASE(3, 2)    // d = 40

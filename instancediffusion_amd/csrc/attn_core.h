@@ -1,4 +1,4 @@
-// attn_core.h -- parameter block shared by the two attention translation units (attention.hip, attention2.hip).
+// attn_core.h -- parameter block shared by the two attention translation units (attention.hip, attention4.hip).
 #pragma once
 #include "common.h"
 
@@ -19,19 +19,20 @@ struct AttnParams {
 
 }  // namespace idfattn
 
-// 64-queries-per-wave LDS-DMA kernel (attention2.hip); IDF_ATTN2_UNSUPPORTED when the shape does not qualify.
+// 64-queries-per-wave LDS-DMA kernel for d in {24, 40, 56} (attention4.hip): max-free softmax with the reference value
+// folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid.  Returns IDF_ATTN2_UNSUPPORTED when the
+// shape does not qualify (the caller then runs the 32-queries-per-wave kernel of attention.hip).
+// Attention mode (idf_set_tuning(IDF_TUNE_ATTN2), env IDF_ATTN2): 0 = 32-query kernel only, 1 = this kernel when the shape
+// qualifies (default), 2 = the same with the plain block order (A/B of the XCD mapping).
+// The round-1 / round-2 variants this kernel replaced (attention2.hip: classic / lazy / software-pipelined online softmax;
+// attention5.hip: 8-wave ping-pong form) were measured slower and live under tools/ubench/archive/ with their logs in
+// profiles/r02_attn_*.
 #define IDF_ATTN2_UNSUPPORTED (-100)
 #ifndef IDF_ATTN2_DEFAULT
-#define IDF_ATTN2_DEFAULT 5
+#define IDF_ATTN2_DEFAULT 1
 #endif
 #include <atomic>
 extern std::atomic<long long> idf_stat_attn2_launches;   // process-global launch counter (idf_get_stat)
 int idf_attn2_mode();
 int idf_attn2_set_mode(int v);
-int idf_launch_attn2(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
-// variant 4 (attention4.hip): max-free softmax with the reference value folded into the K.Q^T MFMA, K fragments read one
-// tile ahead, XCD-aware 1-D grid.  Selected by attention mode 5; same IDF_ATTN2_UNSUPPORTED contract.
 int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
-// variant 5 (attention5.hip): variant 4 as ONE 8-wave workgroup per 512 queries whose two waves per SIMD alternate between a
-// matrix phase and a scalar phase (modes 9 / 10 / 11).
-int idf_launch_attn5(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);

@@ -624,12 +624,8 @@ extern "C" int idf_set_tuning(int knob, int value) {
     g_big_mode = value;
     return prev;
   }
-  if (knob == IDF_TUNE_GEMM_GEOM) {
-    if (value < 0 || value > 6) return IDF_E_ARG;
-    return idf_big_set_geom(value);
-  }
   if (knob == IDF_TUNE_ATTN2) {
-    if (value < 0 || value > 14) return IDF_E_ARG;
+    if (value < 0 || value > 2) return IDF_E_ARG;
     return idf_attn2_set_mode(value);
   }
   return IDF_E_ARG;
@@ -682,6 +678,44 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   int rc = IDF_E_UNSUPPORTED;
+  if (a->vt_out) {
+    // Fused q | k | v projection: columns [vt_col0, N) are stored transposed into vt_out.  One launch of the persistent
+    // kernel when the shape qualifies; otherwise the two GEMMs it replaces (out = A . W[:vt_col0]^T, then the transposed-V
+    // projection vt = W[vt_col0:] . A^T with the LayerNorm statistics on its column side) -- same results up to fp32
+    // summation order, so the caller never has to know which form ran.
+    const int Nv = a->N - a->vt_col0;
+    if (a->vt_col0 <= 0 || Nv <= 0 || batch != 1 || a->ld_vt < a->M || (a->ld_vt % 8) || !aligned16(a->vt_out)) return IDF_E_ARG;
+    if (a->epi & ~(IDF_EPI_BIAS | IDF_EPI_LN_ROW)) return IDF_E_ARG;
+    if (a->out_stats) return IDF_E_ARG;
+    const bool self_ln = (a->epi & IDF_EPI_LN_ROW) && !a->ln_stats;
+    if (self_ln && !a->ln_stats_out) return IDF_E_ARG;        // the fallback's second GEMM needs them somewhere
+    p.vt_out = (unsigned short*)a->vt_out; p.ld_vt = a->ld_vt; p.vt_col0 = a->vt_col0;
+    if (gemm_big_mode() > 0) {
+      const int r = idf_launch_big(p, a->dtype, false, gemm_big_mode() == 2, s, nullptr);
+      if (r != IDF_BIG_UNSUPPORTED) return r;
+    }
+    CoreParams p1 = p;                                          // q | k: the first vt_col0 columns
+    p1.vt_out = nullptr; p1.vt_col0 = 0; p1.N = a->vt_col0; p1.n_valid = a->vt_col0;
+    if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p1, 1, s);
+    else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p1, 1, s);
+    if (rc) return rc;
+    CoreParams p2{};                                            // V^T[Nv, M] = Wv[Nv, K] . A[M, K]^T
+    p2.A = p.W + (size_t)a->vt_col0 * p.ldw; p2.lda = p.ldw; p2.M = Nv; p2.K = a->K;
+    p2.W = p.A; p2.ldw = p.lda; p2.N = a->M; p2.n_valid = a->M;
+    p2.out = a->vt_out; p2.ldo = a->ld_vt;
+    p2.ws = p.ws; p2.ws_bytes = p.ws_bytes;
+    p2.epi = 0;
+    if (a->epi & IDF_EPI_LN_ROW) {
+      p2.epi |= IDF_EPI_LN_COL;
+      p2.ln_stats = self_ln ? a->ln_stats_out : a->ln_stats; p2.stride_ln_stats = 0;
+      p2.ln_c = a->ln_c + a->vt_col0; p2.ln_d = a->bias + a->vt_col0;
+    } else if (a->epi & IDF_EPI_BIAS) {
+      return IDF_E_UNSUPPORTED;                                 // a per-row bias of the transposed product: no caller needs it
+    }
+    if (a->dtype == IDF_BF16) return launch<IDF_BF16, false>(p2, 1, s);
+    if (a->dtype == IDF_F16) return launch<IDF_F16, false>(p2, 1, s);
+    return IDF_E_UNSUPPORTED;
+  }
   if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p, batch, s);
   else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p, batch, s);
   if (rc == 0 && a->out_stats)

@@ -21,6 +21,8 @@ struct CoreParams {
   // LN_ROW with ln_stats == nullptr: the kernel computes (mu, rstd) of A's rows itself (eps = ln_eps) and, when
   // ln_stats_out != nullptr, leaves them there ([M][2]) for an LN_COL consumer of the same matrix
   float ln_eps; float* ln_stats_out;
+  // fused q | k | v projection: output columns n >= vt_col0 are stored transposed, vt_out[(n - vt_col0) * ld_vt + m]
+  unsigned short* vt_out; int ld_vt; int vt_col0;
 };
 
 constexpr int BK = 64;
@@ -118,11 +120,6 @@ __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, in
 
 // Big-tile persistent kernel (gemm_big.hip).  Returns IDF_BIG_UNSUPPORTED when the shape does not qualify.
 #define IDF_BIG_UNSUPPORTED (-100)
-#ifndef IDF_GEMM_GEOM_DEFAULT
-#define IDF_GEMM_GEOM_DEFAULT 0
-#endif
 extern std::atomic<long long> idf_stat_big_launches;     // process-global launch counter (idf_get_stat)
-int idf_big_geom();
-int idf_big_set_geom(int v);
 // *splitk_out > 1 on return: the kernel left fp32 partials of that many K-slices in p.ws; the caller runs the reducer
 int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out);

@@ -45,13 +45,17 @@ __global__ void unifusion_embed_kernel(const float* __restrict__ text, const flo
   out[i] = Elem<DT>::from_f32(v);
 }
 
-// first conv (Cin = 4): NCHW fp32 latent -> NHWC 16-bit.  One thread per (pixel, 8 output channels); the fp32 weights
-// (Cout*Cin*9 floats, 46 KB for 320x4) are staged once per workgroup in LDS as [tap][ci][co] so a thread's 8 output
-// channels read two 16-B LDS vectors per (tap, ci).  One workgroup = 256/cg... pixels x all channel groups.
+// first conv (Cin = 4): NCHW fp32 latent -> NHWC 16-bit.  HBM-bound on the output (B*H*W*Cout*2 B; 168 MB at 64 rows of
+// 64x64x320).  Round 3: PERSISTENT workgroups (two per CU) stage the fp32 weights (Cout*Cin*9 floats, 46 KB for 320x4) in
+// LDS ONCE as [tap][ci][co] and then walk the (pixel quad, 8-channel group) work items grid-stride -- round 2 re-staged and
+// transposed the whole weight tensor for every 64 pixels (361 us per launch = 0.46 TB/s).  A thread owns 8 output channels
+// of FOUR horizontally adjacent pixels: the two 16-B weight vectors of a (tap, ci) are read from LDS once per quad
+// (LDS traffic / 4), the 6 input values of a (ci, ky) row are shared by the quad's 3 x 4 (kx, pixel) products; threads of
+// one quad differ in the channel group only, so their input reads broadcast and their 16-B stores tile a pixel's row.
 template <int DT>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, unsigned short* __restrict__ out,
-                                                     int B, int Cin, int H, int W, int Cout, int pix_per_block) {
+                                                     int B, int Cin, int H, int W, int Cout) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [9*Cin][Cout]
   const int K = 9 * Cin;
   for (int i = threadIdx.x; i < K * Cout; i += 256) {
@@ -61,36 +65,52 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const int cg = Cout >> 3;
-  const size_t npix = (size_t)B * H * W;
-  const size_t pix0 = (size_t)blockIdx.x * pix_per_block;
-  for (int it = threadIdx.x; it < pix_per_block * cg; it += 256) {
-    const int g = it % cg;
-    const size_t pix = pix0 + it / cg;
-    if (pix >= npix) break;
-    const int b = (int)(pix / (H * W)), r = (int)(pix - (size_t)b * H * W);
-    const int y = r / W, xx = r - y * W;
-    float acc[8];
+  const int Wq = (W + 3) >> 2;
+  const long long items = (long long)B * H * Wq * cg;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+    const int g = (int)(it % cg);
+    const long long q = it / cg;
+    const int xq = (int)(q % Wq);
+    const long long r = q / Wq;
+    const int y = (int)(r % H), b = (int)(r / H);
+    const int x0 = xq * 4;
+    float acc[4][8];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + g * 8), b1 = *reinterpret_cast<const f32x4*>(bias + g * 8 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+      for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[pq][j] = b0[j]; acc[pq][j + 4] = b1[j]; }
+    }
     for (int ci = 0; ci < Cin; ++ci) {
       const float* xp = x + ((size_t)b * Cin + ci) * H * W;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int yy = y + ky - 1;
         if (yy < 0 || yy >= H) continue;
+        float xv[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const int xc = x0 - 1 + t;
+          xv[t] = (xc >= 0 && xc < W) ? xp[yy * W + xc] : 0.0f;
+        }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int xc = xx + kx - 1;
-          if (xc < 0 || xc >= W) continue;
-          const float xv = xp[yy * W + xc];
           const float* wp = wl + ((ky * 3 + kx) * Cin + ci) * Cout + g * 8;
           const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { acc[j] = fmaf(xv, w0[j], acc[j]); acc[j + 4] = fmaf(xv, w1[j], acc[j + 4]); }
+          for (int pq = 0; pq < 4; ++pq) {
+            const float v = xv[pq + kx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[pq][j] = fmaf(v, w0[j], acc[pq][j]); acc[pq][j + 4] = fmaf(v, w1[j], acc[pq][j + 4]); }
+          }
         }
       }
     }
-    *reinterpret_cast<u32x4*>(out + pix * Cout + g * 8) = pack8<DT>(acc);
+    unsigned short* op = out + (((size_t)b * H + y) * W + x0) * Cout + g * 8;
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq)
+      if (x0 + pq < W) *reinterpret_cast<u32x4*>(op + (size_t)pq * Cout) = pack8<DT>(acc[pq]);
   }
 }
 
@@ -255,11 +275,17 @@ extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bia
       attr_set[v] = true;
     }
   }
-  const int ppb = 64;                                           // pixels per workgroup
-  const long long npix = (long long)B * H * W;
-  dim3 grid((unsigned)((npix + ppb - 1) / ppb));
-  if (dtype == IDF_BF16) hipLaunchKernelGGL(conv_in_kernel<IDF_BF16>, grid, dim3(256), smem, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout, ppb);
-  else if (dtype == IDF_F16) hipLaunchKernelGGL(conv_in_kernel<IDF_F16>, grid, dim3(256), smem, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout, ppb);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n_cu = n;
+  }
+  const long long items = (long long)B * H * ((W + 3) / 4) * (Cout / 8);
+  const long long need = (items + 255) / 256;
+  dim3 grid((unsigned)(need < 2ll * n_cu ? need : 2ll * n_cu));   // persistent: the weights are staged once per workgroup
+  if (dtype == IDF_BF16) hipLaunchKernelGGL(conv_in_kernel<IDF_BF16>, grid, dim3(256), smem, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout);
+  else if (dtype == IDF_F16) hipLaunchKernelGGL(conv_in_kernel<IDF_F16>, grid, dim3(256), smem, s, x_nchw, w, bias, (unsigned short*)out, B, Cin, H, W, Cout);
   else return IDF_E_UNSUPPORTED;
   return idf_launch_status();
 }

@@ -179,8 +179,15 @@ class UNetEngine:
         """Attention projections behind LayerNorm `norm` (applied to the QUERY side input; for self-attention also to K / V)."""
         d = dict(out=self._lin(a.to_out[0]))
         if self_attn:
-            d["wqk"], d["cqk"], d["dqk"] = self._fold_ln(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach()], 0), None, norm)
-            d["wv"], d["cv"], d["dv"] = self._fold_ln(a.to_v.weight, None, norm)
+            # ONE gamma-folded [3C, C] image: rows [0, 2C) = q | k, rows [2C, 3C) = v.  The fused projection (tokens >= 1024:
+            # V^T in the batch-interleaved global layout) runs on the whole image; the small levels use its two row ranges
+            # as the separate q | k and transposed-V GEMMs (views, no second copy).
+            w3, c3, d3 = self._fold_ln(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach(), a.to_v.weight.detach()], 0),
+                                       None, norm)
+            C2 = 2 * a.to_q.weight.shape[0]
+            d["wqkv"], d["cqkv"], d["dqkv"] = w3, c3, d3
+            d["wqk"], d["cqk"], d["dqk"] = w3[:C2], c3[:C2], d3[:C2]
+            d["wv"], d["cv"], d["dv"] = w3[C2:], c3[C2:], d3[C2:]
         else:                                        # cross attention: K / V come from the (un-normalised) text context
             d["wq"], d["cq"], d["dq"] = self._fold_ln(a.to_q.weight, None, norm)
             d["wk"], d["wv"] = self._w16(a.to_k.weight), self._w16(a.to_v.weight)
@@ -518,22 +525,26 @@ class UNetEngine:
         into the projections (``_fold_ln``).  Returns the attention output [B, N, C] (pre out-proj).
         ``vis``: (qbits, kbits0, kbits1) visibility words of the masked gated self-attention, or None."""
         ops = self.ops
-        # the q/k projection computes the LayerNorm statistics of y's rows in its own K loop and leaves them in st for the
-        # transposed-V projection below
-        if self._ln_self(C):
-            qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(None, a["cqk"]),
-                          ln_stats_out=st).view(B, N, 2 * C)
-        else:
-            qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(st, a["cqk"])).view(B, N, 2 * C)
-        if self.vt_global and N % 64 == 0 and N >= 1024:
-            # V^T in the batch-interleaved image [C][B][N]: ONE unbatched GEMM  V^T = Wv . X^T  over all B*N tokens
-            # (M = C, N = B*N: served by the persistent big-tile kernel) instead of B small batched ones; the
-            # attention kernel reads sample b through (base + b*N, ld = B*N) -- no kernel change, no extra copy.
-            # Measured at 64 rows (profiles/r01_vt_gemm_ab.log): C=320/N=4096 174 -> 114 us, C=640/N=1024 102 -> 89 us,
-            # bitwise-equal output; at N=256 the batched form is 5 % faster, hence the N >= 1024 gate.
-            vtg = ops.gemm(a["wv"], y, self.buf("st.vtg", (C, B * N)), ln_col=(st, a["cv"], a["dv"]))
+        fused = self.vt_global and N % 64 == 0 and N >= 1024
+        if fused:
+            # fused q | k | v projection (round 3): ONE GEMM over the [3C, C] image reads y once; its last C columns are
+            # stored TRANSPOSED straight into the batch-interleaved V^T image [C][B][N] (the attention kernel reads sample b
+            # through base + b*N, ld = B*N), replacing the second GEMM V^T = Wv . y^T (M = C: 62 % tile padding at C = 320)
+            # that re-read y.  The LayerNorm statistics come from the K loop itself where that is free (C = 320), else `st`.
+            vtg = self.buf("st.vtg", (C, B * N))
+            own = self._ln_self(C)
+            qk = ops.gemm(y, a["wqkv"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqkv"],
+                          ln_row=(None if own else st, a["cqkv"]), ln_stats_out=st if own else None,
+                          vt_out=vtg).view(B, N, 2 * C)
             vt = vtg.view(C, B, N).permute(1, 0, 2)
         else:
+            # the q/k projection computes the LayerNorm statistics of y's rows in its own K loop and leaves them in st for
+            # the transposed-V projection below
+            if self._ln_self(C):
+                qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(None, a["cqk"]),
+                              ln_stats_out=st).view(B, N, 2 * C)
+            else:
+                qk = ops.gemm(y, a["wqk"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqk"], ln_row=(st, a["cqk"])).view(B, N, 2 * C)
             ldv = _round_up(N, 64)
             vt = self.buf("st.vt", (B, C, ldv), zero=True)
             ops.gemm(a["wv"], y.view(B, N, C), vt[:, :, :N], ln_col=(st.view(B, N, 2), a["cv"], a["dv"]))

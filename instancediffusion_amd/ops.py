@@ -68,13 +68,14 @@ class HipOps:
     # ------------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None,
              act: Optional[str] = None, geglu: bool = False, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5,
-             ln_eps=1e-5, ln_stats_out=None):
+             ln_eps=1e-5, ln_stats_out=None, vt_out=None):
         """out[..,M,N] = epi(a[..,M,K] @ w[..,N,K]^T).  2-D or batched 3-D views; a/w may be shared (2-D) in a
         batched call.  geglu: ``w``/``bias`` are in the packed [32 value | 32 gate] row order, out has N/2 cols.
         ln_row = (stats [.., M, 2], c [N]): ``a`` is the RAW input of a LayerNorm whose gamma is folded into ``w`` and whose
         beta term travels in ``bias`` (include/idf.h IDF_EPI_LN_ROW).  ln_col = (stats [.., N, 2], c [M], d [M]): the same
         with the normalised operand on the ``w`` side (transposed-V projection).  out_stats [.., M, 2]: also emit (mu, rstd)
-        of every output row for a LayerNorm that follows."""
+        of every output row for a LayerNorm that follows.  vt_out [N - out.shape[-1], >= M]: fused q | k | v projection --
+        the product's columns beyond out's width are stored transposed there (include/idf.h)."""
         batched = out.dim() == 3
         M, K = a.shape[-2], a.shape[-1]
         N = w.shape[-2]
@@ -102,6 +103,9 @@ class HipOps:
         if geglu:
             epi |= EPI_GEGLU
             assert out.shape[-1] == N // 2
+        elif vt_out is not None:
+            assert not batched and out.shape[-2] == M and vt_out.shape[0] == N - out.shape[-1] and vt_out.shape[1] >= M
+            assert vt_out.stride(1) == 1 and vt_out.dtype == self.dtype
         else:
             assert out.shape[-1] == N and out.shape[-2] == M
         if out.dtype == torch.float32:
@@ -139,7 +143,9 @@ class HipOps:
             ln_stats=None if ln_stats is None else ln_stats.data_ptr(), stride_ln_stats=s_ln,
             ln_c=None if ln_c is None else ln_c.data_ptr(), ln_d=None if ln_d is None else ln_d.data_ptr(),
             out_stats=None if out_stats is None else out_stats.data_ptr(), out_stats_eps=float(out_stats_eps),
-            ln_eps=float(ln_eps), ln_stats_out=None if ln_stats_out is None else ln_stats_out.data_ptr())
+            ln_eps=float(ln_eps), ln_stats_out=None if ln_stats_out is None else ln_stats_out.data_ptr(),
+            vt_out=None if vt_out is None else vt_out.data_ptr(), ld_vt=0 if vt_out is None else vt_out.stride(0),
+            vt_col0=0 if vt_out is None else out.shape[-1])
         _lib.check(self.lib.idf_gemm(C.byref(args), self._stream()), "idf_gemm")
         return out
 

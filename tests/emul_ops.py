@@ -42,7 +42,7 @@ class EmulOps:
 
     # ----------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None, act=None, geglu=False,
-             ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5, ln_eps=1e-5, ln_stats_out=None):
+             ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5, ln_eps=1e-5, ln_stats_out=None, vt_out=None):
         self._count("gemm")
         assert a.dtype == self.dtype and w.dtype == self.dtype
         assert a.shape[-1] % 64 == 0, "K % 64"
@@ -80,6 +80,12 @@ class EmulOps:
             return out
         if bias is not None:
             acc = acc + bias
+        if vt_out is not None:                         # fused q | k | v: trailing columns stored transposed (include/idf.h)
+            assert rowbias is None and res is None and act is None and out_stats is None and acc.dim() == 2
+            n_out = out.shape[-1]
+            out.copy_(acc[:, :n_out])
+            vt_out[:, :acc.shape[0]] = acc[:, n_out:].t().to(vt_out.dtype)
+            return out
         if rowbias is not None:
             M = acc.shape[-2]
             idx = torch.arange(M) // rows_per_batch

@@ -153,3 +153,42 @@ def test_broadcast_mask_stack_is_tokenized_once():
     assert torch.allclose(t_rep, t_bc, atol=1e-6) and t_bc.shape[0] == 3
     assert e1.ops.calls["seg_in_conv"] == 1 and e2.ops.calls["seg_in_conv"] == 1
     assert e2.ops.calls["dwconv7x7"] == e1.ops.calls["dwconv7x7"]        # same launches, one third of the rows
+
+
+def test_fused_qkv_projection_equals_the_two_gemm_form():
+    """At >= 1024 tokens per sample the engine issues ONE q | k | v GEMM whose last C columns land transposed in the
+    batch-interleaved V^T image (``vt_out``, include/idf.h); below, and with IDF_VT_GLOBAL=0, the q | k GEMM plus the
+    transposed-V GEMM it replaced.  Same forward either way (32x32 latent on the 3-level model: the 320-channel level has
+    1024 tokens), also against the CPU oracle; the fused call count is checked."""
+    from oracle import ref_cpu
+    cfg = cases.cfg_for("test_box.yaml", "mid")
+    model = build_model(cfg)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    from instancediffusion_amd import synth
+    gb = synth.make_grounding_batch(2, synth.random_boxes(3, g), g)
+    x = torch.randn(2, 4, 32, 32, generator=g)
+    ctx = torch.randn(2, 77, 768, generator=g)
+    t = torch.tensor([700.0, 300.0])
+    grounding = GroundingNetInput().prepare(gb)
+    outs = []
+    with torch.no_grad():
+        for vt_global in (True, False):
+            ops = EmulOps(torch.float32)
+            fused_calls = [0]
+            real = ops.gemm
+
+            def counting(*a, _real=real, **k):
+                fused_calls[0] += k.get("vt_out") is not None
+                return _real(*a, **k)
+            ops.gemm = counting
+            eng = UNetEngine(model, ops=ops, use_graphs=False)
+            eng.vt_global = vt_global
+            cond = eng.prepare_cond(ctx, grounding)
+            outs.append(eng.forward_cond(x, t, cond))
+            n_top = sum(1 for p in eng._st_layers() if p["c"] == 320)
+            assert fused_calls[0] == (2 * n_top if vt_global else 0)          # self + gated self-attention per layer
+        objs, _ = ref_cpu.unifusion(sd, cfg, ref_cpu.prepare_grounding(gb))
+        want = ref_cpu.unet_forward(sd, cfg, x, t.long(), ctx, objs)
+    assert cases.rel_rms(outs[0], outs[1]) < 1e-5
+    assert cases.rel_rms(outs[0], want) < 3e-4

@@ -187,3 +187,64 @@ def test_non_power_of_two_latent_matches_live_oracle():
         assert tok_err < 2e-2
         eps = eng.forward_cond(x.cuda(), t.cuda(), cond)
     _check(eps, want, "mid test_mask 48x48 latent, live oracle", "mid_box")
+
+
+def _stat(which):
+    from instancediffusion_amd import _lib
+    return int(_lib.load().idf_get_stat(which))
+
+
+def _forward_at_bench_width(tag, dtype):
+    """The forward the BENCH runs: 64 rows = 32 conditional + 32 null-grounding rows, as PLMSSamplerInst forms them
+    (host/samplers.py: one [cond | uncond] batch per 32 units), with DEFAULT dispatch.  Every engine / sampler golden is a
+    batch-1..3 forward whose tile grids fail the persistent kernel's round-efficiency gate (gemm_big.hip), so those run the
+    128^2 fallback kernels; here M = 64 x H x W rows and the counters must show that ``gemm_kernel_big`` and the 64-query
+    LDS-DMA attention served the launches.  The 64 rows are 32 copies of the golden's conditional input and 32 of its
+    unconditional one: every row is held to the reference golden, and copies must be bitwise equal to each other."""
+    from grounding_input.text_grounding_tokinzer_input import GroundingNetInput
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import Cond
+    gold, meta, cfg, inp = _case(tag)
+    model = _build(cfg)
+    model.compute_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    gi = GroundingNetInput()
+    model.grounding_tokenizer_input = gi
+    g = {k: v.cuda() for k, v in gi.prepare(inp["gb"]).items()}
+    gi.prepare({k: v.cuda() for k, v in inp["gb"].items()})
+    eng = model.engine
+    n = 32
+    with torch.no_grad():
+        c = eng.prepare_cond(inp["context"].cuda(), g)
+        u = eng.prepare_cond(inp["uc"].cuda(), gi.get_null_input(batch=1))
+        bank = Cond.cat([c, u])
+        slot = eng.gather_cond(bank, torch.tensor([0] * n + [1] * n, device="cuda"))
+        x = inp["x"].cuda().float().repeat(2 * n, 1, 1, 1)
+        t = inp["t"].cuda().float().repeat(2 * n)
+        big0, att0 = _stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), _stat(_lib.IDF_STAT_ATTN2_LAUNCHES)
+        eng.use_graphs = False
+        eps = eng.forward_cond(x, t, slot)
+        big1, att1 = _stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), _stat(_lib.IDF_STAT_ATTN2_LAUNCHES)
+        eng.use_graphs = True
+        eps_g = eng.forward_cond(x, t, slot)                     # warm-up + capture + replay
+        eps_g2 = eng.forward_cond(x, t, slot)
+    n_st = eng.n_st
+    print(f"[dispatch] {tag} {dtype} 64-row forward: {big1 - big0} persistent big-tile GEMM/conv launches, "
+          f"{att1 - att0} LDS-DMA 64-query attention launches ({n_st} transformer layers)")
+    assert big1 - big0 >= 150, "the benched GEMM / conv kernel did not serve this forward"
+    assert att1 - att0 >= 10, "the benched d = 40 attention kernel did not serve this forward"
+    assert torch.equal(eps, eps_g) and torch.equal(eps_g, eps_g2), "hipGraph replay must equal the eager launch sequence"
+    assert all(torch.equal(eps[i], eps[0]) for i in range(1, n)), "identical conditional rows must be bitwise equal"
+    assert all(torch.equal(eps[n + i], eps[n]) for i in range(1, n)), "identical unconditional rows must be bitwise equal"
+    _check(eps[:1], gold["eps_cond"], f"{tag} 64-row forward (default dispatch), cond rows", tag, dtype)
+    _check(eps[n:n + 1], gold["eps_uncond"], f"{tag} 64-row forward (default dispatch), uncond rows", tag, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_full_size_forward_at_bench_width_default_dispatch(dtype):
+    """parity at the kernel selection the bench runs (full 1.228 B model, 64x64 latent, C1 golden)."""
+    _forward_at_bench_width("full_box_c1", dtype)
+
+
+def test_full_size_c4_forward_at_bench_width_default_dispatch():
+    """The same at BASELINE config 4's size: 96x96 latent, 12 instance masks (9216 + 184 keys in the d = 40 attention)."""
+    _forward_at_bench_width("full_mask_c4", "bf16")

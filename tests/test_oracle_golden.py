@@ -80,6 +80,24 @@ def test_samplers_match_reference(tag):
 
 
 @heavy
+def test_full_model_headline_trajectory_matches_reference():
+    """The headline trajectory on the headline model (golden ``full_box_s50``: the unmodified reference PLMSSamplerInst, full
+    1.228 B-parameter UNet, 64x64 latent, S = 50, N = 8, mis 0.36, alpha [0.8, 0, 0.2]): 406 full-size CPU forwards of the
+    oracle (~20 min on 8 cores) -- opt-in; the recorded result of one run is profiles/r03_oracle_full_s50.log."""
+    gold, meta, cfg, sd, inp = _setup("full_box_s50")
+    with torch.no_grad():
+        g = ref_cpu.prepare_grounding(inp["gb"])
+        model = ref_cpu.OracleModel(sd, cfg, synth.synth_first_conv_sd())
+        inputs = [dict(x=inp["x"].clone(), timesteps=None, context=inp["context"], grounding_input=g)]
+        for i in range(meta["n_inst"]):
+            gi = ref_cpu.prepare_grounding(synth.instance_batch(inp["gb"], i))
+            inputs.append(dict(x=inp["x"].clone(), timesteps=None, context=inp["inst_ctx"][i], grounding_input=gi))
+        out = ref_cpu.plms_sample_mis(model, meta["S"], inputs, inp["uc"], 7.5, meta["mis"], alpha_type=meta["alpha_type"])
+    print(f"[oracle] full_box_s50 MIS trajectory vs the reference golden: rel-rms {cases.rel_rms(out, gold['mis']):.3e}")
+    _check(out, gold["mis"], TRAJ_TOL, "full-model MIS trajectory")
+
+
+@heavy
 def test_full_size_c4_forward_matches_reference():
     """BASELINE config 4 at its stated size: test_mask.yaml, 96x96 latent, 12 masks with segs + polygons (ConvNeXt live)."""
     gold, meta, cfg, sd, inp = _setup("full_mask_c4")

@@ -142,3 +142,55 @@ def test_mis_crop_and_paste_on_gpu_vs_oracle():
     err = cases.rel_rms(out.cpu(), want)
     print(f"[parity] tiny_box MIS crop-and-paste S={S}: latent rel-rms {err:.3e} (tol {TRAJ_TOL[torch.bfloat16]:.0e})")
     assert torch.isfinite(out).all() and err < TRAJ_TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_full_model_headline_trajectory_s50_n8_at_bench_width(dtype):
+    """THE headline trajectory on THE headline model.  Golden = the unmodified reference
+    ``PLMSSamplerInst`` (plms_instance.py:59-158) on the full 1.228 B-parameter UNet, B = 1, 64x64 latent, S = 50
+    (inference.py:64), N = 8 boxes, mis 0.36, alpha [0.8, 0, 0.2] with the first-conv swap at step 40, CFG 7.5: 406 chained
+    CPU forwards (``oracle/make_golden.py --only full_s50``).  Here the same inputs are replicated to 32 images so that the
+    sampler forms exactly the bench's forwards (9 chunks of 32 units = 64-row phase-1 forwards with 4096 + 184 keys in the
+    d = 40 attention, 64-row phase-2 forwards, default dispatch, hipGraph replay).  Besides the final latent, the merged
+    latent (the mean over the N+1 instance latents after 18 steps) is compared with the reference's."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.samplers import PLMSSamplerInst
+    from tests import cases
+    gold, meta, inp, model, gi, diffusion = _setup("full_box_s50", dtype)
+    assert meta["S"] == 50 and meta["n_inst"] == 8 and meta["latent"] == 64 and meta["variant"] == "full"
+    R = 32
+
+    def rep(v):
+        return v.cuda().repeat(R, *([1] * (v.dim() - 1)))
+    big = dict(x=rep(inp["x"]), context=rep(inp["context"]), uc=rep(inp["uc"]), inst_ctx=[rep(c) for c in inp["inst_ctx"]],
+               gb={k: (v.cuda().expand(R, *v.shape[1:]) if k == "segs" else rep(v)) for k, v in inp["gb"].items()})
+    inputs = _mis_inputs(big, gi, meta)
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
+                              set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+    ops = model.engine.ops
+    seen = {}
+    real_merge = ops.mis_merge
+
+    def merge(lat, boxes, out, mode):
+        r = real_merge(lat, boxes, out, mode)
+        seen["merged"] = r.clone()
+        return r
+    ops.mis_merge = merge
+    lib = _lib.load()
+    big0, att0 = lib.idf_get_stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), lib.idf_get_stat(_lib.IDF_STAT_ATTN2_LAUNCHES)
+    out = sampler.sample(S=meta["S"], shape=(R, 4, 64, 64), input=inputs, uc=big["uc"], guidance_scale=7.5)
+    ops.mis_merge = real_merge
+    big1, att1 = lib.idf_get_stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), lib.idf_get_stat(_lib.IDF_STAT_ATTN2_LAUNCHES)
+    assert big1 > big0 and att1 > att0, "the captured forwards must contain the benched kernels"
+    out_c = out.float().cpu()
+    assert torch.isfinite(out_c).all()
+    same = all(torch.equal(out_c[i], out_c[0]) for i in range(1, R))
+    spread = max(cases.rel_rms(out_c[i:i + 1], out_c[:1]) for i in range(1, R))
+    err = cases.rel_rms(out_c[:1], gold["mis"])
+    err_m = cases.rel_rms(seen["merged"][:1].float().cpu(), gold["marks"]["merged"])
+    print(f"[parity] full model MIS S=50 N=8 mis=0.36 alpha [0.8,0,0.2] {dtype}, 32 images (64-row forwards): final latent "
+          f"rel-rms {err:.3e} (tol {TRAJ_TOL[dtype]:.0e}), merged latent after 18 steps {err_m:.3e}; the 32 identical images "
+          f"{'are bitwise equal' if same else f'differ by {spread:.2e}'}")
+    assert err < TRAJ_TOL[dtype] and err_m < TRAJ_TOL[dtype]
+    assert same, "identical images must give bitwise identical latents whatever chunk / row they were computed in"

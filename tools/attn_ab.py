@@ -1,5 +1,6 @@
-"""A/B of the attention variants on the headline shapes (MI355X box): python tools/attn_ab.py [batch=64] [modes=3,5,6]
-Prints TFLOP/s per (shape, mode); mode = IDF_TUNE_ATTN2 value (0 = 32-query kernel, 3 = variant 2 lazy, 5 = variant 4)."""
+"""A/B of the attention kernels on the headline shapes (MI355X box): python tools/attn_ab.py [batch=64] [modes=1,2,0]
+Prints TFLOP/s per (shape, mode); mode = IDF_TUNE_ATTN2 value (0 = 32-query kernel only, 1 = 64-query LDS-DMA kernel for d = 40
+(default), 2 = the same with the plain block order).  d = 80 / 160 / cross-attention always run the 32-query kernel."""
 import json
 import os
 import sys
@@ -11,7 +12,7 @@ from instancediffusion_amd import _lib  # noqa: E402
 from instancediffusion_amd.ops import HipOps  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-modes = [int(m) for m in (sys.argv[2] if len(sys.argv) > 2 else "3,5,6").split(",")]
+modes = [int(m) for m in (sys.argv[2] if len(sys.argv) > 2 else "1,2,0").split(",")]
 dt = torch.float16 if os.environ.get("ATTN_AB_DTYPE") == "fp16" else torch.bfloat16
 ops = HipOps(dt)
 lib = _lib.load()

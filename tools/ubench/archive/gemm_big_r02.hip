@@ -20,15 +20,9 @@
 // Round 2 (profiles/r02_*): the LDS-DMA pieces are inline assembly and the second half of the workgroup enqueues them from
 // the middle of its K-tile (fill schedule, see the K loop); split-K work items for grids that leave most CUs idle
 // (SPLIT); LayerNorm folded into the epilogue (IDF_EPI_LN_ROW / LN_COL) with the row statistics optionally summed in the
-// K loop itself (LNS); 128-wide tiles with three stages.  What bounds the K loop: tools/ubench/dma_rate.hip -- a wave moves
-// 5.6 B/clk from L2 into LDS, a CU 34 B/clk, the 256 x 320 tile needs 28.8 B/clk at 100 % MFMA.
-// Round 3: (a) the geometries that were measured slower (two 4-wave workgroups per CU, the role-split ping-pong kernel, the
-// four-stage 32-deep ring, the end / spread fill schedules) left the library -- source snapshot
-// tools/ubench/archive/gemm_big_r02.hip, numbers profiles/r02_pp_*, r02_shape_profile_B64_fill_*; (b) fused q | k | v
-// projection (VT): the output tiles whose columns lie at or beyond `vt_col0` run the SAME K loop with the MFMA operands
-// swapped, so a lane ends up with 16 consecutive TOKENS of one channel and stores V transposed (V^T[channel][token], the
-// layout the P.V MFMA's A operand wants) -- one launch reads the activation tile once for q, k and V^T instead of a second
-// GEMM (M = C, whose 256-row tiles were 62 % padding at C = 320) re-reading it.
+// K loop itself (LNS); 128-wide tiles with three stages; a role-split ping-pong variant of the same tile
+// (gemm_kernel_pp, geometry 2: measured slower, kept for A/B).  What bounds the K loop: tools/ubench/dma_rate.hip --
+// a wave moves 5.6 B/clk from L2 into LDS, a CU 34 B/clk, the 256 x 320 tile needs 28.8 B/clk at 100 % MFMA.
 //
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops 2*M*N*K.  LDS image and XOR swizzle are the ones
 // of gemm_kernel_dma (linear 128-B rows, 16-B slot ^= (row >> 1) & 7 applied on the global source address).
@@ -241,71 +235,12 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
   }
 }
 
-// Epilogue of a TRANSPOSED tile (fused q | k | v projection, columns >= vt_col0): the K loop ran with the MFMA operands
-// swapped, acc[a][b][4q+e] = D[m = b*32 + 8q + 4hi + e][n = a*32 + l31]; the same two v_permlane32_swap per register pair
-// now leave a lane with 16 consecutive TOKENS m = b*32 + 16*hi + [0,16) of channel n = a*32 + l31: two 16-B stores into
-// V^T[n - vt_col0][m ..].  LayerNorm folded in as in LN_ROW (the statistics belong to the tokens: 16 (mu, rstd) pairs per
-// lane -- read as 8 float4, or with LNS fetched from the lanes that summed those rows in the K loop), c[n] and the beta /
-// bias term d[n] are per-lane scalars.  Requires M % 16 == 0.
-template <int DT, int BM, int BN, int TN, bool LNS>
-__device__ __forceinline__ void big_epilogue_vt(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int tiles_n, int wm, int wn,
-                                                int l31, int hi, const float* lnm, const float* lnr) {
-  constexpr int WN = BN / 2;
-  const int epi = p.epi;
-  const int m_tile = seq / tiles_n;
-  const int n0 = (seq - m_tile * tiles_n) * BN, m0 = m_tile * BM;
-  const int mw = m0 + wm * WM, nw = n0 + wn * WN;
-  auto swap16 = [&](const f32x16& c, float* v) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[e]), __float_as_uint(c[8 + e]), false, false);
-      const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[4 + e]), __float_as_uint(c[12 + e]), false, false);
-      v[e] = __uint_as_float(s02[0]); v[4 + e] = __uint_as_float(s02[1]);
-      v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
-    }
-  };
-#pragma unroll
-  for (int b = 0; b < TM; ++b) {
-    const int mb = mw + b * 32 + 16 * hi;                  // first of this lane's 16 tokens
-    float mu[16], rs[16];
-    if (epi & IDF_EPI_LN_ROW) {
-      if constexpr (LNS) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { mu[j] = __shfl(lnm[b], 16 * hi + j, 64); rs[j] = __shfl(lnr[b], 16 * hi + j, 64); }
-      } else {
-        const f32x4* st4 = reinterpret_cast<const f32x4*>(p.ln_stats + 2 * (size_t)min(mb, p.M - 16));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const f32x4 t = st4[j]; mu[2 * j] = t[0]; rs[2 * j] = t[1]; mu[2 * j + 1] = t[2]; rs[2 * j + 1] = t[3]; }
-      }
-    }
-    static_for<0, TN, 1>([&](auto AI) {
-      constexpr int a = decltype(AI)::value;
-      const int n = nw + a * 32 + l31;
-      float v[16];
-      swap16(acc[a][b], v);
-      if (epi & IDF_EPI_LN_ROW) {
-        const float cn = p.ln_c[n];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = rs[j] * fmaf(-mu[j], cn, v[j]);
-      }
-      if (epi & IDF_EPI_BIAS) {
-        const float bn = p.bias[n];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] += bn;
-      }
-      if (mb < p.M) {
-        unsigned short* o = p.vt_out + (size_t)(n - p.vt_col0) * p.ld_vt + mb;
-        *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
-        *reinterpret_cast<u32x4*>(o + 8) = pack8<DT>(v + 8);
-      }
-    });
-  }
-}
-
 // Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
-//   <256, {320,256}, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages); <256, 128, 64, 3>: 3 x 48 KB stages.
-template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false>
-__global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
+//   <256, BN, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages).
+//   <128, BN, 32, 3|2>: TWO independent 4-wave workgroups per CU (their barriers, DMA waits and epilogues interleave on
+//   the SIMDs instead of coinciding); 64-B LDS rows, 16-B slot ^= (row >> 2) & 3.
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false>
+__global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 1)) void gemm_kernel_big(const CoreParams p, const int tiles_total, const int skew) {
   constexpr int WN = BN / 2, TN = WN / 32;
   constexpr int NW = BM / 32;                              // waves per workgroup (8 or 4)
   constexpr int RS = BKT;                                  // LDS row stride (elements): linear rows, no padding
@@ -411,11 +346,9 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   int issued = 0;                                         // K-tiles enqueued so far
   float lsx[TM], lsq[TM];                                 // LNS: per-lane partial sum / sum of squares of its A rows
   constexpr int NPOS = (BKT / 16) * TN;                   // (k-step, weight fragment) positions of a K-tile: TM MFMAs each
-  // `late_fill`: this wave enqueues the next K-tile's LDS-DMA pieces from the MIDDLE of its MFMAs (see the K loop).
-  // SWAPT: MFMA operands swapped (transposed-V tiles of the fused q | k | v projection): acc[a][b] then holds
-  // D[m = b*32 + 8q + 4hi + e][n = a*32 + l31] -- a lane owns a channel, its registers run over tokens.
-  auto compute = [&](auto SWAPT, int stage, bool late_fill, int st_fill) {
-    constexpr bool SWAP = decltype(SWAPT)::value;
+  // fill modes (`skew`, see the K loop): 0 burst before the MFMAs; 1 / 2: the second half of the workgroup bursts after the
+  // middle / last position; 3: one piece every second position, the two halves on alternating positions
+  auto compute = [&](int stage, int mode, int par, int st_fill) {
     const unsigned short* Al = smem + stage * STAGE;
     const unsigned short* Wl = Al + BM * RS;
     const unsigned short* af_base = Al + (wm * WM + l31) * RS;
@@ -442,10 +375,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         constexpr int a = decltype(AI)::value;
         constexpr int pos = ks * TN + a;
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
-          if constexpr (SWAP) acc[a][b] = Elem<DT>::mfma32(af[cur][b], wf[cur][a], acc[a][b]);
-          else acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
-        }
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
         if constexpr (LNS && a == 0) {                      // row sums of the A fragments this k-step multiplies: 16 VALU ops
 #pragma unroll
           for (int b = 0; b < TM; ++b)
@@ -455,12 +385,19 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
               Elem<DT>::dot2c(lsq[b], af[cur][b][w], af[cur][b][w]);
             }
         }
+        if constexpr (pos / 2 < DPW) {
+          if (mode == 3 && ((pos & 1) ^ par)) issue_piece(st_fill, IC<pos / 2>{});
+        }
         if constexpr (pos == NPOS / 2 - 1) {
-          if (late_fill) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
+          if (mode == 1 && par) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
         }
       });
     });
-    if (late_fill) { advance_loader(); ++issued; }
+    if (mode == 2 && par) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
+    if constexpr (2 * DPW > NPOS) {                       // spread mode, short K-tiles: the pieces that found no position
+      if (mode == 3) static_for<NPOS / 2, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
+    }
+    if (mode > 0) { advance_loader(); ++issued; }
   };
 
   int seq = slot;
@@ -484,8 +421,6 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 #pragma unroll
     for (int b = 0; b < TM; ++b) { lsx[b] = 0.0f; lsq[b] = 0.0f; }
-    // fused q | k | v projection: this tile's columns belong to V -> swapped operands, transposed store (workgroup-uniform)
-    const bool vt_tile = VT && ((seq % tiles_n) * BN >= p.vt_col0);
 
     for (int kt = 0; kt < nk; ++kt) {
       // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt
@@ -496,24 +431,23 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       __builtin_amdgcn_s_barrier();                       // ... and every wave has finished reading the stage refilled below
       asm volatile("" ::: "memory");
       // An LDS-DMA instruction holds the issuing wave for ~180-240 cycles (tools/ubench/dma_rate.hip: 5.6 B/clk per wave,
-      // 34 B/clk per CU), during which it issues no MFMA.  The fill is therefore SKEWED: waves 0-3 enqueue the next K-tile
-      // right behind the barrier, waves 4-7 -- the partner wave on every SIMD -- from the middle of their MFMAs, so one wave
-      // of a SIMD feeds the matrix pipe while the other is held in the memory pipe (measured against end-of-tile and spread
-      // schedules in round 2: profiles/r02_shape_profile_B64_fill_*.log).
+      // 34 B/clk per CU), during which it issues no MFMA.  `skew` de-phases the two waves of a SIMD so that one feeds the
+      // matrix pipe while the other is held in the memory pipe: 1 / 2 = the second half of the workgroup enqueues its pieces
+      // from the middle / the end of its K-tile, 3 = every wave spreads its pieces between its MFMAs, the halves alternating.
       const bool fill = l_seq < tiles_total;
       int st_fill = st_it + NSTG - 1;
       if (st_fill >= NSTG) st_fill -= NSTG;
-      const bool late = fill && wave >= NW / 2;
-      if (fill && !late) {
-        issue_dma(st_fill);
-        ++issued;
+      int mode = 0;
+      const int par = wave >= NW / 2 ? 1 : 0;
+      if (fill) {
+        if (skew == 3) mode = 3;
+        else if (skew && par) mode = skew;
+        if (mode == 0) {
+          issue_dma(st_fill);
+          ++issued;
+        }
       }
-      if constexpr (VT) {
-        if (vt_tile) compute(IC<1>{}, st_it, late, st_fill);
-        else compute(IC<0>{}, st_it, late, st_fill);
-      } else {
-        compute(IC<0>{}, st_it, late, st_fill);
-      }
+      compute(st_it, mode, par, st_fill);
       ++it;
       if (++st_it == NSTG) st_it = 0;
     }
@@ -531,16 +465,259 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         lnr[b] = rsqrtf(fmaxf(fmaf(-mu, mu, sq * inv_k), 0.0f) + p.ln_eps);
       }
     }
-    if constexpr (VT) {
-      if (vt_tile) big_epilogue_vt<DT, BM, BN, TN, LNS>(p, acc, seq, tiles_n, wm, wn, l31, hi, lnm, lnr);
-      else big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
-    } else {
-      big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
-    }
+    big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (geometry 2).  Same 256 x BN tile, wave tile, LDS image family (64-B rows, BKT = 32) and epilogue,
+// but the two waves of a SIMD are in OPPOSITE roles: while waves 0-3 run the 20 (16) MFMAs of half-tile H out of
+// registers, waves 4-7 read their fragments of H from LDS (and issue LDS-DMA pieces), and vice versa -- the matrix pipe of
+// a SIMD always has one wave feeding it, the LDS/DMA latencies sit in the partner's slot.  Ring: 4 stages of 32-deep
+// half K-tiles (3 half-tiles = 108 KB in flight per CU against 72 KB in the lock-step kernel, which is what bounds the
+// HBM-streaming K = 320 layers).  Phase p of a tile: X = waves 0-3: L(h) at p = 2h, C(h) at 2h+1;  Y = waves 4-7: L(h) at
+// 2h+1, C(h) at 2h+2; one s_barrier between phases.  Both groups enqueue their pieces of half-tile H+3 during L(H)/C(H)
+// (its stage was last read in phase 2H-1).  A wave makes its own pieces of H visible with a counted `s_waitcnt vmcnt`
+// before the barrier that opens X's L(H): the count is the number of VMEM operations it issued after those pieces
+// (younger DMA pieces, plus the epilogue's stores when they fall in between; loads/stores retire in order on gfx9).
+// Optional per-segment cycle trace (tools/ubench/pp_trace.hip builds this file with -DIDF_PP_TRACE): s_memtime deltas summed
+// per segment over all half-tiles, written by waves 0 and 4 of workgroup 0.
+#ifdef IDF_PP_TRACE
+__device__ unsigned long long idf_pp_trace_buf[2][16];
+#define TR_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define TR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
+#define TR_DUMP if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) { for (int i = 0; i < 12; ++i) idf_pp_trace_buf[wave >> 2][i] = tr_acc[i]; }
+#else
+#define TR_DECL
+#define TR(i)
+#define TR_DUMP
+#endif
+
+template <int DT, int BN, bool CONV, int DL>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_pp(const CoreParams p, const int tiles_total) {
+  constexpr int BM = 256, BKT = 32, NSTG = 4, NW = 8;
+  constexpr int WN = BN / 2, TN = WN / 32;
+  constexpr int RS = BKT, CPR = 4, RPI = 16;
+  constexpr int A_INST = BM / (RPI * NW);                  // 2 activation pieces per wave per half-tile
+  constexpr int W_PIECES = BN / RPI;                       // 20 or 16 weight pieces per half-tile
+  constexpr int W_INST = (W_PIECES + NW - 1) / NW;         // 3 (waves 0-3 of BN = 320) or 2
+  constexpr int NP = A_INST + W_INST;
+  constexpr int STAGE = (BM + BN) * RS;
+  constexpr int NMF = 2 * TN * TM;                         // MFMAs per half-tile per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave & 1, wmm = wave >> 1;                // wave tile: 64-row slab wmm, column half wn
+  const int grp = wave >> 2;                               // role group: waves w and w + 4 share a SIMD
+  const int G = gridDim.x;
+  const int slot = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tiles_n = p.N / BN;
+  const int nh = p.K / BKT;
+  const int my_w = (wave + NW * (W_INST - 1) < W_PIECES) ? W_INST : W_INST - 1;
+  const int P = A_INST + my_w;                             // LDS-DMA pieces this wave issues per half-tile
+  const int P_L = (DL < A_INST ? DL : A_INST) + (DL > A_INST ? ((DL - A_INST) < my_w ? (DL - A_INST) : my_w) : 0);   // ... of them in the L phase
+
+  // ---------------- loader state (flattened (tile, half-tile) stream)
+  const int dr = lane / CPR, dc = lane % CPR;
+  auto swz = [](int row) { return (row >> 2) & 3; };
+  unsigned woff[W_INST], aoff[A_INST];
+  int ayx[A_INST];
+  int l_seq, l_kt = 0, tap = 0, ci0 = 0;
+
+  auto setup_loader = [&](int tile) {
+    const int m_tile = tile / tiles_n;
+    const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
+#pragma unroll
+    for (int j = 0; j < W_INST; ++j) {
+      const int row = min(RPI * (wave + NW * j), BN - RPI) + dr;
+      woff[j] = (unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)((dc ^ swz(row)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < A_INST; ++j) {
+      const int row = RPI * (wave + NW * j) + dr;
+      const int m = min(m0 + row, p.M - 1);
+      const unsigned sw = (unsigned)((dc ^ swz(row)) * 8);
+      if (CONV) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, rem = m - b * hw;
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        ayx[j] = ((yo * p.stride - 1) << 16) | ((xo * p.stride - 1) & 0xffff);
+        aoff[j] = (unsigned)b * (unsigned)(p.Hin * p.Win) * (unsigned)p.lda + sw;
+      } else {
+        ayx[j] = 0;
+        aoff[j] = (unsigned)m * (unsigned)p.lda + sw;
+      }
+    }
+    tap = 0; ci0 = 0;
+  };
+
+  // piece i of the half-tile the loader stands on: i < A_INST activation rows, else weight rows
+  auto issue_piece = [&](int stage, auto II) {
+    constexpr int i = decltype(II)::value;
+    unsigned short* Al = smem + stage * STAGE;
+    if constexpr (i < A_INST) {
+      constexpr int j = i;
+      const unsigned dst = lds_addr(Al + RPI * (wave + NW * j) * RS);
+      if (CONV) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+        const int yi = (ayx[j] >> 16) + ky, xi = (int)(short)(ayx[j] & 0xffff) + kx;
+        const bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
+        const int ys = yi >> p.up, xs = xi >> p.up;
+        const unsigned short* src = ok ? p.A + ci0 + (aoff[j] + (unsigned)(ys * p.Win + xs) * (unsigned)p.lda) : idf_zero_page + dc * 8;
+        dma16_v(src, dst);
+      } else {
+        dma16_sv(p.A + (size_t)l_kt * BKT, aoff[j] * 2u, dst);
+      }
+    } else {
+      constexpr int j = i - A_INST;
+      if (j < W_INST - 1 || wave + NW * j < W_PIECES)
+        dma16_sv(p.W + (size_t)l_kt * BKT, woff[j] * 2u, lds_addr(Al + BM * RS + RPI * (wave + NW * j) * RS));
+    }
+  };
+  auto advance_loader = [&]() {
+    if (CONV) { ci0 += BKT; if (ci0 >= p.Cin) { ci0 = 0; ++tap; } }
+    if (++l_kt == nh) {
+      l_kt = 0;
+      l_seq += G;
+      if (l_seq < tiles_total) setup_loader(l_seq);
+    }
+  };
+
+  // ---------------- fragments / MFMA
+  f32x16 acc[TN][TM];
+  u32x4 wf[2][TN], af[2][TM];
+  const int f_sw = swz(l31);
+  auto load_frags = [&](int stage) {
+    const unsigned short* Al = smem + stage * STAGE;
+    const unsigned short* af_base = Al + (wmm * WM + l31) * RS;
+    const unsigned short* wf_base = Al + BM * RS + (wn * WN + l31) * RS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int s8 = ((ks * 2 + hi) ^ f_sw) * 8;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[ks][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + s8);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[ks][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + s8);
+    }
+  };
+
+  int seq = slot;
+  if (seq >= tiles_total) return;
+  l_seq = seq;
+  setup_loader(l_seq);
+  int issuedH = 0;                                        // half-tiles enqueued so far (by this wave: its own pieces)
+  int fill = 0;                                           // ring stage the next enqueued half-tile goes to
+  int e_issued = 0, e_stores = 0;                         // last epilogue: half-tiles enqueued before its stores, store count
+  auto enqueue_begin = [&]() { return l_seq < tiles_total; };
+  auto enqueue_end = [&]() { advance_loader(); ++issuedH; fill = (fill + 1) & (NSTG - 1); };
+#pragma unroll
+  for (int j = 0; j < NSTG - 1; ++j)
+    if (enqueue_begin()) {
+      static_for<0, NP, 1>([&](auto II) { issue_piece(fill, II); });
+      enqueue_end();
+    }
+  // own pieces of half-tile H landed: at most `younger` VMEM operations issued after them may still be outstanding
+  auto wait_own = [&](int H, int open_pieces) {
+    int younger = (issuedH - 1 - H) * P + (H < e_issued ? e_stores : 0) + open_pieces;
+    younger = younger < 0 ? 0 : younger;
+    switch (younger) {
+#define IDF_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+      IDF_W(0) IDF_W(1) IDF_W(2) IDF_W(3) IDF_W(4) IDF_W(5) IDF_W(6) IDF_W(7) IDF_W(8) IDF_W(9) IDF_W(10) IDF_W(11) IDF_W(12)
+      IDF_W(13) IDF_W(14) IDF_W(15) IDF_W(16) IDF_W(17) IDF_W(18) IDF_W(19) IDF_W(20) IDF_W(21) IDF_W(22) IDF_W(23) IDF_W(24)
+      IDF_W(25) IDF_W(26) IDF_W(27) IDF_W(28) IDF_W(29) IDF_W(30) IDF_W(31) IDF_W(32) IDF_W(33) IDF_W(34) IDF_W(35) IDF_W(36)
+      IDF_W(37) IDF_W(38) IDF_W(39) IDF_W(40)
+#undef IDF_W
+      default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;     // more allowed than encodable here: over-wait
+    }
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  // L phase: fragments of the half-tile in `stage` into registers, the first DL pieces of the next enqueue
+  auto phase_L = [&](int stage, bool enq) {
+    load_frags(stage);
+    if (enq) static_for<0, (DL < NP ? DL : NP), 1>([&](auto II) { issue_piece(fill, II); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // C phase: the MFMAs of the half-tile held in registers, the remaining pieces spread between them
+  auto phase_C = [&](bool enq) {
+    static_for<0, NMF, 1>([&](auto MI) {
+      constexpr int i = decltype(MI)::value;
+      constexpr int ks = i / (TN * TM), a = (i % (TN * TM)) / TM, b = i % TM;
+      acc[a][b] = Elem<DT>::mfma32(wf[ks][a], af[ks][b], acc[a][b]);
+      // one LDS-DMA piece after every third MFMA, starting behind the second
+      if constexpr (i >= 1 && (i - 1) % 3 == 0 && DL + (i - 1) / 3 < NP) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (enq) issue_piece(fill, IC<DL + (i - 1) / 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    static_assert(DL + (NMF - 2) / 3 + 1 >= NP, "not every piece gets a slot between the MFMAs");
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  };
+
+  const float gate = (p.epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+  const int stores_per_tile = (p.epi & IDF_EPI_OUT_F32) ? 0 : ((p.epi & IDF_EPI_GEGLU) ? TN * TM : 2 * TN * TM);
+  int H = 0;                                              // global half-tile index of the stream this wave consumes
+  int stg = 0;                                            // its ring stage
+
+  // One instruction stream for both groups; Y runs it one phase late (an extra barrier at the head of a tile, where X has
+  // one at the tail).  The accumulators are cleared in slack time: X while it would wait for Y's epilogue, Y in its idle
+  // phase 0.
+  TR_DECL
+  for (; seq < tiles_total; seq += G) {
+    if (grp == 1) {
+      wait_own(H, 0);
+      barrier();                                          // phase 0 (Y idle)
+    }
+    zero_acc();
+    TR(9)
+    for (int h = 0; h < nh; ++h) {
+      if (grp == 0) wait_own(H, 0);
+      TR(0)
+      barrier();                                          // X: phase 2h, Y: phase 2h + 1
+      TR(1)
+      const bool enq = enqueue_begin();
+      phase_L(stg, enq);
+      TR(2)
+      if (grp == 1 && h + 1 < nh) wait_own(H + 1, enq ? P_L : 0);
+      TR(3)
+      barrier();                                          // X: phase 2h + 1, Y: phase 2h + 2
+      TR(4)
+      phase_C(enq);
+      TR(5)
+      if (enq) enqueue_end();
+      ++H; stg = (stg + 1) & (NSTG - 1);
+      TR(6)
+    }
+    if (grp == 0) barrier();                              // phase 2 nh: the partner's last C
+    TR(7)
+    big_epilogue<DT, BM, BN, TN, false>(p, acc, seq, 0, tiles_n, wmm, wn, l31, hi, gate);
+    // the stores just issued are younger than every piece enqueued so far (full tiles only: a wave whose rows all lie
+    // beyond M skips its stores, and an over-estimate here would under-wait)
+    const int m_tile = seq / tiles_n;
+    e_issued = issuedH;
+    e_stores = ((m_tile + 1) * BM <= p.M) ? stores_per_tile : 0;
+    TR(8)
+  }
+  TR_DUMP
+}
+
 int g_num_cu = 0;
+int g_geom = -2;                                             // 0: one 8-wave 256-row workgroup per CU, 1: two 4-wave 128-row ones, 2: ping-pong
 
 int num_cu() {
   if (g_num_cu == 0) {
@@ -551,16 +728,15 @@ int num_cu() {
   return g_num_cu;
 }
 
-template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false>
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false>
 int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
-  constexpr int BM = 256, BKT = 64;
-  if constexpr (!SPLIT && !LNS && !VT && NSTG == 2) {
-    if (splitk > 1) return launch_big_cfg<DT, BN, NSTG, CONV, true>(p, s, splitk);
+  if constexpr (!SPLIT && !LNS && BM == 256) {
+    if (splitk > 1) return launch_big_cfg<DT, BM, BN, BKT, NSTG, CONV, true>(p, s, splitk);
   }
-  if constexpr (!SPLIT && !LNS && !CONV && NSTG == 2) {
-    if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT>(p, s, 1);
+  if constexpr (!SPLIT && !LNS && !CONV && BM == 256 && BKT == 64) {
+    if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BM, BN, BKT, NSTG, CONV, false, true>(p, s, 1);
   }
-  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT>;
+  void (*kern)(const CoreParams, const int, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS>;
   constexpr int smem = NSTG * (BM + BN) * BKT * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -571,15 +747,48 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   CoreParams q = p;
   q.splitk = splitk; q.kt_per_slice = p.K / BKT / splitk;
   const int tiles = (p.N / BN) * ((p.M + BM - 1) / BM) * splitk;   // work items
-  const int slots = num_cu();
+  const int slots = num_cu() * (BM == 128 ? 2 : 1);
   const int grid = tiles < slots ? tiles : slots;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(BM * 2), smem, s, q, tiles);
+  // fill schedule (kernel comment): geometry 3 / 4 / 5 force skew 2 / 1 / 3; geometry 0 = the measured default per K
+  const int geom = idf_big_geom();
+  int skew = 0;
+  if (geom == 3) skew = 2;
+  else if (geom == 5) skew = 3;
+  else if (geom == 0 || geom == 4 || geom == 6) skew = 1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BM * 2), smem, s, q, tiles, skew);
   return idf_launch_status();
 }
+
+template <int DT, int BN, bool CONV, int DL>
+int launch_pp_cfg(const CoreParams& p, hipStream_t s) {
+  void (*kern)(const CoreParams, const int) = gemm_kernel_pp<DT, BN, CONV, DL>;
+  constexpr int smem = 4 * (256 + BN) * 32 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  CoreParams q = p;
+  q.splitk = 1; q.kt_per_slice = p.K / 32;
+  const int tiles = (p.N / BN) * ((p.M + 255) / 256);
+  const int slots = num_cu();
+  const int grid = tiles < slots ? tiles : slots;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, q, tiles);
+  return idf_launch_status();
+}
+
+int g_pp_dl = -1;
 
 }  // namespace
 
 std::atomic<long long> idf_stat_big_launches{0};
+
+int idf_big_geom() {
+  if (g_geom == -2) { const char* e = getenv("IDF_GEMM_GEOM"); g_geom = e ? atoi(e) : IDF_GEMM_GEOM_DEFAULT; }
+  return g_geom;
+}
+int idf_big_set_geom(int v) { const int prev = idf_big_geom(); g_geom = v; return prev; }
 
 // Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
 int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out) {
@@ -594,27 +803,23 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if (!aligned16(p.out) || ((p.epi & IDF_EPI_RES) && !aligned16(p.res)) || ((p.epi & IDF_EPI_ROWBIAS) && !aligned16(p.rowbias)) ||
       ((p.epi & (IDF_EPI_BIAS | IDF_EPI_GEGLU)) && !aligned16(p.bias))) return IDF_BIG_UNSUPPORTED;
   if ((p.epi & (IDF_EPI_LN_ROW | IDF_EPI_LN_COL)) && (!aligned16(p.ln_c) || !aligned16(p.ln_stats))) return IDF_BIG_UNSUPPORTED;
-  // self-normalising LN_ROW (no statistics passed): computed in the K loop of the dense kernel
+  // self-normalising LN_ROW (no statistics passed): only the lock-step 256-row kernel computes them in its K loop
   const bool self_ln = (p.epi & IDF_EPI_LN_ROW) && !p.ln_stats;
-  if (self_ln && conv) return IDF_BIG_UNSUPPORTED;
-  // fused q | k | v projection: the transposed tiles are 320 wide and start on a tile boundary; their epilogue takes
-  // LN_ROW / BIAS only and stores 16 tokens per lane
-  const bool vt = p.vt_out != nullptr;
-  if (vt && (conv || geglu || (p.N % 320) || (p.vt_col0 % 320) || p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.M % 16) || (p.ld_vt % 8) ||
-             !aligned16(p.vt_out) || (p.epi & ~(IDF_EPI_BIAS | IDF_EPI_LN_ROW)))) return IDF_BIG_UNSUPPORTED;
+  if (self_ln && (conv || idf_big_geom() == 1 || idf_big_geom() == 2 || idf_big_geom() == 6)) return IDF_BIG_UNSUPPORTED;
+  const int geom = idf_big_geom();
   int bn = 0;
   if (geglu) bn = (p.N % 256 == 0) ? 256 : 0;
   else if (p.N % 320 == 0) bn = 320;
   else if (p.N % 256 == 0) bn = 256;
-  else if (p.N % 128 == 0 && !self_ln) bn = 128;
+  else if (p.N % 128 == 0 && geom != 1 && geom != 2 && !self_ln) bn = 128;
   if (!bn) return IDF_BIG_UNSUPPORTED;
-  const int bm = 256;
-  const long long slots = (long long)num_cu();
+  const int bm = geom == 1 ? 128 : 256;
+  const long long slots = (long long)num_cu() * (geom == 1 ? 2 : 1);
   const long long tiles = (long long)(p.N / bn) * ((p.M + bm - 1) / bm);
   // split-K: when the tile grid leaves most CUs idle and K is long (the 8x8-level convs and ff-out GEMMs: 64 tiles of
   // 180..360 K-tiles), S slices per tile (S | K-tiles, >= 16 K-tiles each) leave fp32 partials in the caller's workspace
   int splitk = 1;
-  if (splitk_out && bn != 128 && !geglu && !self_ln && !vt && p.ws && tiles * 2 <= slots) {
+  if (splitk_out && geom != 1 && geom != 2 && bn != 128 && !geglu && !self_ln && p.ws && tiles * 2 <= slots) {
     const int nkt = p.K / BK;
     for (int cand = (int)(slots / tiles); cand >= 2; --cand) {
       if (nkt % cand || nkt / cand < 16) continue;
@@ -636,16 +841,34 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
     if (rows * (unsigned long long)p.lda >= (1ull << 31) || (unsigned long long)p.N * p.ldw >= (1ull << 31)) return IDF_BIG_UNSUPPORTED;
   }
   ++idf_stat_big_launches;
+  if (g_pp_dl < 0) { const char* e = getenv("IDF_GEMM_PP_DL"); g_pp_dl = e ? atoi(e) : 3; }
+#define IDF_PP_DISPATCH(DT, DLV)                                                                                          \
+  {                                                                                                                       \
+    if (conv) return bn == 320 ? launch_pp_cfg<DT, 320, true, DLV>(p, s) : launch_pp_cfg<DT, 256, true, DLV>(p, s);       \
+    return bn == 320 ? launch_pp_cfg<DT, 320, false, DLV>(p, s) : launch_pp_cfg<DT, 256, false, DLV>(p, s);               \
+  }
 #define IDF_BIG_DISPATCH(DT)                                                                                              \
-  if (vt) return launch_big_cfg<DT, 320, 2, false, false, false, true>(p, s);                                             \
-  if (bn == 128) {                       /* 128-wide tiles (the VAE's 128-channel convs at 512^2): 3 stages of 48 KB */  \
-    if (conv) return launch_big_cfg<DT, 128, 3, true>(p, s);                                                              \
-    return launch_big_cfg<DT, 128, 3, false>(p, s);                                                                       \
+  if (geom == 2) {                                                                                                        \
+    if (g_pp_dl == 0) IDF_PP_DISPATCH(DT, 0)                                                                              \
+    IDF_PP_DISPATCH(DT, 3)                                                                                                \
   }                                                                                                                       \
-  if (conv) return bn == 320 ? launch_big_cfg<DT, 320, 2, true>(p, s, splitk) : launch_big_cfg<DT, 256, 2, true>(p, s, splitk);     \
-  return bn == 320 ? launch_big_cfg<DT, 320, 2, false>(p, s, splitk) : launch_big_cfg<DT, 256, 2, false>(p, s, splitk);
+  if (geom == 1) {                                                                                                        \
+    if (conv) return bn == 320 ? launch_big_cfg<DT, 128, 320, 32, 2, true>(p, s) : launch_big_cfg<DT, 128, 256, 32, 3, true>(p, s);   \
+    return bn == 320 ? launch_big_cfg<DT, 128, 320, 32, 2, false>(p, s) : launch_big_cfg<DT, 128, 256, 32, 3, false>(p, s);           \
+  }                                                                                                                       \
+  if (geom == 6 && bn == 256 && splitk == 1) {                                                                            \
+    if (conv) return launch_big_cfg<DT, 256, 256, 32, 4, true>(p, s);                                                     \
+    return launch_big_cfg<DT, 256, 256, 32, 4, false>(p, s);                                                              \
+  }                                                                                                                       \
+  if (bn == 128) {                       /* 128-wide tiles (the VAE's 128-channel convs at 512^2): 3 stages of 48 KB */  \
+    if (conv) return launch_big_cfg<DT, 256, 128, 64, 3, true>(p, s);                                                     \
+    return launch_big_cfg<DT, 256, 128, 64, 3, false>(p, s);                                                              \
+  }                                                                                                                       \
+  if (conv) return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, true>(p, s, splitk) : launch_big_cfg<DT, 256, 256, 64, 2, true>(p, s, splitk);     \
+  return bn == 320 ? launch_big_cfg<DT, 256, 320, 64, 2, false>(p, s, splitk) : launch_big_cfg<DT, 256, 256, 64, 2, false>(p, s, splitk);
   if (dtype == IDF_BF16) { IDF_BIG_DISPATCH(IDF_BF16) }
   if (dtype == IDF_F16) { IDF_BIG_DISPATCH(IDF_F16) }
 #undef IDF_BIG_DISPATCH
+#undef IDF_PP_DISPATCH
   return IDF_E_UNSUPPORTED;
 }

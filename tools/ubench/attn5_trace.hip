@@ -4,7 +4,7 @@
 //         tools/ubench/attn5_trace.hip -o tools/ubench/attn5_trace
 // Segments (s_memtime cycles summed over the tiles of one block, waves 0 and 4): 1 DMA issue, 2 P.V (16 MFMA), 3 K.Q^T
 // (12 MFMA), 4 counted vmcnt wait, 5 barrier after M, 6 S phase (exp / pack / guard / fragment reads), 7 barrier after S.
-#include "attention5.hip"
+#include "archive/attention5.hip"
 #include <cstdio>
 #include <cstring>
 #include <vector>

@@ -5,7 +5,7 @@
 //   0 counted vmcnt wait (X)  1 barrier before L  2 L: fragment reads (+ DL pieces) and their lgkmcnt wait
 //   3 counted vmcnt wait (Y)  4 barrier before C  5 C: MFMAs + LDS-DMA pieces  6 loader advance
 //   per tile: 7 tail barrier (X)  8 epilogue  9 head barrier (Y) + accumulator clear
-#include "gemm_big.hip"
+#include "archive/gemm_big_r02.hip"
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {

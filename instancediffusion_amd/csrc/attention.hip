@@ -47,12 +47,14 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  // XCD-aware block order (round 3): hardware block L (x fastest) runs on XCD L % 8 and every XCD has its own L2.  In
-  // launch order the query blocks of one (batch, head) land on 8 different XCDs and each of them fetches that head's K / V^T
-  // (PMC at batch 64, d = 80: 6.1x the algorithmic fetch bytes).  Give every XCD a CONTIGUOUS range of the logical
-  // (b, h, query block) list instead: the blocks sharing a K / V^T slice share an L2.
+  // XCD-aware block order (round 3), resident-key (cross-attention) launches only: hardware block L (x fastest) runs on XCD
+  // L % 8 and every XCD has its own L2; giving every XCD a CONTIGUOUS range of the logical (b, h, query block) list keeps the
+  // workgroups that stage the same 77 keys on one L2 (64^2 cross-attention 183 -> 128 us at batch 64).  The streaming
+  // launches (d = 80 / 160 self-attention) measured 3-5 % SLOWER with the same mapping -- their over-fetch is absorbed by the
+  // Infinity Cache, and eight CUs of one XCD then pull the same K / V^T lines through one L2 channel at the same time --
+  // so they keep the plain order (profiles/r03_shape_profile_B64_a.log vs r02_shape_profile_B64_fill_middle.log).
   int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  {
+  if (RES) {
     const int gx = gridDim.x, gy = gridDim.y;
     const int total = gx * gy * (int)gridDim.z;
     if ((total & 7) == 0) {

@@ -242,64 +242,53 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
 }
 
 // Epilogue of a TRANSPOSED tile (fused q | k | v projection, columns >= vt_col0): the K loop ran with the MFMA operands
-// swapped, acc[a][b][4q+e] = D[m = b*32 + 8q + 4hi + e][n = a*32 + l31]; the same two v_permlane32_swap per register pair
-// now leave a lane with 16 consecutive TOKENS m = b*32 + 16*hi + [0,16) of channel n = a*32 + l31: two 16-B stores into
-// V^T[n - vt_col0][m ..].  LayerNorm folded in as in LN_ROW (the statistics belong to the tokens: 16 (mu, rstd) pairs per
-// lane -- read as 8 float4, or with LNS fetched from the lanes that summed those rows in the K loop), c[n] and the beta /
-// bias term d[n] are per-lane scalars.  Requires M % 16 == 0.
-template <int DT, int BM, int BN, int TN, bool LNS>
+// swapped, acc[a][b][4q+e] = D[m = b*32 + 8q + 4hi + e][n = a*32 + l31]; two v_permlane32_swap per register pair now leave a
+// lane with 8 consecutive TOKENS of channel n = a*32 + l31 per half (q in {0,2}: tokens 16*hi + [0,8), q in {1,3}: + [8,16)):
+// one 16-B store into V^T[n - vt_col0][m ..] each.  LayerNorm folded in as in LN_ROW, but here the statistics belong to the
+// register dimension: 8 (mu, rstd) pairs per half, read as 4 float4 from `stats` -- the caller's array, or (LNS) the
+// wave's own LDS copy of what it summed in the K loop -- per (a, b, half) so that no more than 16 of them are live next
+// to the 160 accumulators; c[n] and the beta / bias term d[n] are per-lane scalars.  Requires M % 16 == 0.
+template <int DT, int BM, int BN, int TN>
 __device__ __forceinline__ void big_epilogue_vt(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int tiles_n, int wm, int wn,
-                                                int l31, int hi, const float* lnm, const float* lnr) {
+                                                int l31, int hi, const float* stats /* (mu, rstd) pairs */, int stats_row0) {
   constexpr int WN = BN / 2;
   const int epi = p.epi;
   const int m_tile = seq / tiles_n;
   const int n0 = (seq - m_tile * tiles_n) * BN, m0 = m_tile * BM;
   const int mw = m0 + wm * WM, nw = n0 + wn * WN;
-  auto swap16 = [&](const f32x16& c, float* v) {
+  static_for<0, TN, 1>([&](auto AI) {
+    constexpr int a = decltype(AI)::value;
+    const int n = nw + a * 32 + l31;
+    const float cn = (epi & IDF_EPI_LN_ROW) ? p.ln_c[n] : 0.0f;
+    const float bn = (epi & IDF_EPI_BIAS) ? p.bias[n] : 0.0f;
+    unsigned short* orow = p.vt_out + (size_t)(n - p.vt_col0) * p.ld_vt;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[e]), __float_as_uint(c[8 + e]), false, false);
-      const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[4 + e]), __float_as_uint(c[12 + e]), false, false);
-      v[e] = __uint_as_float(s02[0]); v[4 + e] = __uint_as_float(s02[1]);
-      v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
-    }
-  };
+    for (int b = 0; b < TM; ++b) {
 #pragma unroll
-  for (int b = 0; b < TM; ++b) {
-    const int mb = mw + b * 32 + 16 * hi;                  // first of this lane's 16 tokens
-    float mu[16], rs[16];
-    if (epi & IDF_EPI_LN_ROW) {
-      if constexpr (LNS) {
+      for (int half = 0; half < 2; ++half) {                 // registers q = half, half + 2
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { mu[j] = __shfl(lnm[b], 16 * hi + j, 64); rs[j] = __shfl(lnr[b], 16 * hi + j, 64); }
-      } else {
-        const f32x4* st4 = reinterpret_cast<const f32x4*>(p.ln_stats + 2 * (size_t)min(mb, p.M - 16));
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][4 * half + e]),
+                                                           __float_as_uint(acc[a][b][4 * half + 8 + e]), false, false);
+          v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+        }
+        const int mb = mw + b * 32 + 16 * hi + 8 * half;      // first of these 8 tokens
+        if (epi & IDF_EPI_LN_ROW) {
+          const f32x4* st4 = reinterpret_cast<const f32x4*>(stats + 2 * (size_t)(min(mb, p.M - 8) - stats_row0));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const f32x4 t = st4[j]; mu[2 * j] = t[0]; rs[2 * j] = t[1]; mu[2 * j + 1] = t[2]; rs[2 * j + 1] = t[3]; }
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 t = st4[j];                           // (mu, rstd) of tokens mb + 2j, mb + 2j + 1
+            v[2 * j] = t[1] * fmaf(-t[0], cn, v[2 * j]);
+            v[2 * j + 1] = t[3] * fmaf(-t[2], cn, v[2 * j + 1]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bn;
+        if (mb < p.M) *reinterpret_cast<u32x4*>(orow + mb) = pack8<DT>(v);
       }
     }
-    static_for<0, TN, 1>([&](auto AI) {
-      constexpr int a = decltype(AI)::value;
-      const int n = nw + a * 32 + l31;
-      float v[16];
-      swap16(acc[a][b], v);
-      if (epi & IDF_EPI_LN_ROW) {
-        const float cn = p.ln_c[n];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = rs[j] * fmaf(-mu[j], cn, v[j]);
-      }
-      if (epi & IDF_EPI_BIAS) {
-        const float bn = p.bias[n];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] += bn;
-      }
-      if (mb < p.M) {
-        unsigned short* o = p.vt_out + (size_t)(n - p.vt_col0) * p.ld_vt + mb;
-        *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
-        *reinterpret_cast<u32x4*>(o + 8) = pack8<DT>(v + 8);
-      }
-    });
-  }
+  });
 }
 
 // Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
@@ -406,15 +395,13 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   };
 
   // ---------------- MFMA side
-  f32x16 acc[TN][TM];
   const int f_sw = swz(l31);                              // fragment rows are (multiple of 32) + l31
   int issued = 0;                                         // K-tiles enqueued so far
-  float lsx[TM], lsq[TM];                                 // LNS: per-lane partial sum / sum of squares of its A rows
   constexpr int NPOS = (BKT / 16) * TN;                   // (k-step, weight fragment) positions of a K-tile: TM MFMAs each
   // `late_fill`: this wave enqueues the next K-tile's LDS-DMA pieces from the MIDDLE of its MFMAs (see the K loop).
   // SWAPT: MFMA operands swapped (transposed-V tiles of the fused q | k | v projection): acc[a][b] then holds
   // D[m = b*32 + 8q + 4hi + e][n = a*32 + l31] -- a lane owns a channel, its registers run over tokens.
-  auto compute = [&](auto SWAPT, int stage, bool late_fill, int st_fill) {
+  auto compute = [&](auto SWAPT, f32x16 (&acc)[TN][TM], float (&lsx)[TM], float (&lsq)[TM], int stage, bool late_fill, int st_fill) {
     constexpr bool SWAP = decltype(SWAPT)::value;
     const unsigned short* Al = smem + stage * STAGE;
     const unsigned short* Wl = Al + BM * RS;
@@ -475,7 +462,13 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
 
-  for (; seq < tiles_total; seq += G) {
+  // One output tile: accumulators cleared, the K loop, the epilogue.  SWAPT = the transposed-V tiles of the fused q | k | v
+  // projection.  The accumulators are LOCAL to a tile kind: with one accumulator block shared by the plain and the swapped
+  // K loop the register allocator kept both MFMA forms' tied operands alive and spilled ~400 VGPRs (80 TF instead of 700).
+  auto run_tile = [&](auto SWAPT) {
+    constexpr bool SWAP = decltype(SWAPT)::value;
+    f32x16 acc[TN][TM];
+    float lsx[TM], lsq[TM];                               // LNS: per-lane partial sum / sum of squares of its A rows
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -484,8 +477,6 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 #pragma unroll
     for (int b = 0; b < TM; ++b) { lsx[b] = 0.0f; lsq[b] = 0.0f; }
-    // fused q | k | v projection: this tile's columns belong to V -> swapped operands, transposed store (workgroup-uniform)
-    const bool vt_tile = VT && ((seq % tiles_n) * BN >= p.vt_col0);
 
     for (int kt = 0; kt < nk; ++kt) {
       // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt
@@ -508,17 +499,12 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         issue_dma(st_fill);
         ++issued;
       }
-      if constexpr (VT) {
-        if (vt_tile) compute(IC<1>{}, st_it, late, st_fill);
-        else compute(IC<0>{}, st_it, late, st_fill);
-      } else {
-        compute(IC<0>{}, st_it, late, st_fill);
-      }
+      compute(SWAPT, acc, lsx, lsq, st_it, late, st_fill);
       ++it;
       if (++st_it == NSTG) st_it = 0;
     }
 
-    // epilogue of tile seq: no LDS, no barrier -- a wave that finishes its MFMAs early runs its epilogue while the other
+    // epilogue of tile seq: no workgroup barrier -- a wave that finishes its MFMAs early runs its epilogue while the other
     // wave of its SIMD is still in the K-loop
     float lnm[TM], lnr[TM];
     if constexpr (LNS) {                                    // a row's 8-element chunks alternate between the lane halves
@@ -531,11 +517,33 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         lnr[b] = rsqrtf(fmaxf(fmaf(-mu, mu, sq * inv_k), 0.0f) + p.ln_eps);
       }
     }
-    if constexpr (VT) {
-      if (vt_tile) big_epilogue_vt<DT, BM, BN, TN, LNS>(p, acc, seq, tiles_n, wm, wn, l31, hi, lnm, lnr);
-      else big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
+    if constexpr (SWAP) {
+      if constexpr (LNS) {
+        // the statistics this wave summed in the K loop, parked in its own LDS slice (behind the ring) so that the
+        // transposed epilogue can read the pair of ANY of the wave's 64 rows: [row][2], row = b*32 + l31
+        float* stw = reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 128;
+        if (hi == 0) {
+#pragma unroll
+          for (int b = 0; b < TM; ++b) *reinterpret_cast<f32x2*>(stw + 2 * (b * 32 + l31)) = f32x2{lnm[b], lnr[b]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, stw, (seq / tiles_n) * BM + wm * WM);
+      } else {
+        big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, p.ln_stats, 0);
+      }
     } else {
       big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
+    }
+  };
+
+  for (; seq < tiles_total; seq += G) {
+    if constexpr (VT) {
+      // fused q | k | v projection: this tile's columns belong to V -> swapped operands, transposed store (workgroup-uniform)
+      if ((seq % tiles_n) * BN >= p.vt_col0) run_tile(IC<1>{});
+      else run_tile(IC<0>{});
+    } else {
+      run_tile(IC<0>{});
     }
   }
 }
@@ -561,7 +569,7 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
     if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT>(p, s, 1);
   }
   void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT>;
-  constexpr int smem = NSTG * (BM + BN) * BKT * 2;
+  constexpr int smem = NSTG * (BM + BN) * BKT * 2 + ((VT && LNS) ? 8 * 128 * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

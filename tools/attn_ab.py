@@ -51,12 +51,18 @@ for (N, d, n1, tag) in [(4096, 40, 0, "self 64^2"), (4096, 40, 184, "gated 64^2"
     o = ops.empty((Bx, N, C))
     kw = dict(k1=rnd(Bx, 184, C), vt1=rnd(Bx, C, 192), n1=184) if n1 else {}
     flops = 4.0 * Bx * N * (n0 + n1) * C
-    outs = {}
+    outs, best = {}, {}
+    call = lambda: ops.attention(q, k0, vt0, n0, o, 8, **kw)      # noqa: E731
+    timeit(call, iters=5, warm=3)                                 # clock / cache warm-up: the first timed mode is not penalised
+    for rep in range(3):                                          # interleaved repetitions, best of three per mode
+        for m in modes:
+            prev = lib.idf_set_tuning(1, m)
+            sec = timeit(call)
+            outs[m] = o.float().clone()
+            lib.idf_set_tuning(1, prev)
+            best[m] = min(best.get(m, 1e9), sec)
     for m in modes:
-        prev = lib.idf_set_tuning(1, m)
-        sec = timeit(lambda: ops.attention(q, k0, vt0, n0, o, 8, **kw))
-        outs[m] = o.float().clone()
-        lib.idf_set_tuning(1, prev)
+        sec = best[m]
         r = dict(shape=tag, B=Bx, d=d, mode=m, us=round(sec * 1e6, 1), tflops=round(flops / sec / 1e12, 1),
                  frac_mfma=round(flops / sec / 2.5e15, 4))
         if m != modes[0]:

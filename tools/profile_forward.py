@@ -1,6 +1,8 @@
 """rocprofv3 target: a few eager UNet forwards of the FULL model at the MIS phase-1 batch (18 = 9 trajectories x
 cond/uncond) through the C ABI.  Used for the per-kernel stats and the FETCH_SIZE / WRITE_SIZE PMC passes
-(separate runs; see profiles/README.md).  Usage: python tools/profile_forward.py [batch] [iters]"""
+(separate runs; see profiles/README.md).  Usage: python tools/profile_forward.py [batch] [iters] [graph]
+With a third argument the forwards are hipGraph replays (as the samplers run them) and the wall time per replay is printed:
+together with the kernel-trace sum of the same run that separates kernel time from launch / dependency gaps."""
 import os
 import sys
 
@@ -18,11 +20,20 @@ dev = torch.device("cuda", 0)
 inputs, uc, gi, _ = bench.make_inputs(cfg, batch, dev)
 model.grounding_tokenizer_input = gi
 eng = model.engine
-eng.use_graphs = False
+graph = len(sys.argv) > 3
+eng.use_graphs = graph
 cond = eng.prepare_cond(inputs[0]["context"], inputs[0]["grounding_input"])
 x = torch.randn(batch, 4, 64, 64, device=dev)
 t = torch.full((batch,), 500.0, device=dev)
+if graph:
+    import time
+    for _ in range(3):
+        eps = eng.forward_cond(x, t, cond)                   # eager warm-up, capture, first replays
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
 for _ in range(iters):
     eps = eng.forward_cond(x, t, cond)
 torch.cuda.synchronize()
+if graph:
+    print(f"graph replay: {(time.perf_counter() - t0) / iters * 1e3:.3f} ms per {batch}-row forward ({iters} replays)")
 print("ok", float(eps.abs().mean()))

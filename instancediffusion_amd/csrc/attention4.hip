@@ -67,8 +67,12 @@ template <> struct RefShift<IDF_F16> { static constexpr float v = 1.0f; };     /
 
 // VA = how many tiles ahead V^T is fetched (1: 2-stage ring, wait for everything at the end of a tile; 2: 3-stage ring like K,
 // and the end-of-tile wait leaves the loads issued in THIS tile in flight -- they have two tiles to land).
-template <int DT, int NKS, int NMT, int VA>
-__global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const int nqb, const int xcd_order) {
+// NW = waves per workgroup (64 queries each).  4: two independent workgroups per CU (their phases drift apart, which overlaps
+// one's MFMAs with the other's exponentials).  8: ONE workgroup per CU sharing every K / V^T tile among twice as many waves --
+// an LDS-DMA instruction holds its issuing wave ~180+ cycles (tools/ubench/dma_rate.hip), and with 11 KB per tile that is
+// 2.75 instructions per wave and tile at NW = 4, 1.4 at NW = 8 (the default since round 3; A/B: profiles/r03_attn_ab2_B64.log).
+template <int DT, int NKS, int NMT, int VA, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, const int nqb, const int xcd_order) {
   constexpr int DCH = 2 * NKS - 1;                 // 16-B chunks per K row
   constexpr int D = 8 * DCH;                       // head dim
   constexpr int KSZ = KVT * D;                     // K stage (elements), linear rows of D*2 bytes (D/8 odd: conflict-free)
@@ -76,10 +80,12 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   constexpr int VSZ = VROWS * KVT;                 // V^T stage (elements), 128-B rows, 16-B slot ^= (row >> 1) & 7
   constexpr int K_INST = DCH;                      // LDS-DMA instructions per K tile (64 chunks each)
   constexpr int V_INST = D / 8;                    // per V^T tile (8 rows each); instruction V_INST = the ones-row group
-  constexpr int K_PER_WAVE = (K_INST + 3) / 4, V_PER_WAVE = (V_INST + 3) / 4;
+  constexpr int NT = NW * 64;                      // threads per workgroup
+  constexpr int K_PER_WAVE = (K_INST + NW - 1) / NW, V_PER_WAVE = (V_INST + NW - 1) / NW;
   static_assert(D < 32 * NMT && (D % 8) == 0 && D + 8 <= VROWS, "needs a spare 8-row group for the softmax denominator");
   constexpr int VST = VA + 1;                      // V^T ring stages
-  __shared__ __attribute__((aligned(128))) unsigned short smem[3 * KSZ + VST * VSZ + 8];
+  constexpr int RING = 3 * KSZ + VST * VSZ + 8, OSTAGE = NW * 64 * D;        // K / V^T rings; O staging block of the epilogue
+  __shared__ __attribute__((aligned(128))) unsigned short smem[RING > OSTAGE ? RING : OSTAGE];
   __shared__ int redo_flag;                        // some wave met an inf / nan P: redo the block with the exact per-tile max
   unsigned short* const Ks = smem;
   unsigned short* const Vs = smem + 3 * KSZ;
@@ -99,11 +105,11 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   const int b = L / (nqb * p.H);
 
   // zero the V^T ring once (pad rows of the O^T tile must be finite zeros), then the ones row and the ones fragment
-  for (int i = tid; i < VST * VSZ / 2; i += 256) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
+  for (int i = tid; i < VST * VSZ / 2; i += NT) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
   __syncthreads();
   {
     const unsigned short one = Elem<DT>::from_f32(1.0f);
-    for (int i = tid; i < VST * KVT; i += 256) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
+    for (int i = tid; i < VST * KVT; i += NT) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
     if (tid < 8) ones_frag[tid] = tid == 0 ? one : (unsigned short)0;
     if (tid == 0) redo_flag = 0;
   }
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   int qrow[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    qrow[g] = qb * 256 + wave * 64 + g * 32 + l31;
+    qrow[g] = qb * NT + wave * 64 + g * 32 + l31;
     const int qr = min(qrow[g], p.nq - 1);
     const unsigned short* qp = p.q + (size_t)b * p.sQ + (size_t)qr * p.ldq + h * D;
 #pragma unroll
@@ -142,19 +148,19 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   // global 8-key chunk slot ^ ((row >> 1) & 7)).  K instruction i is issued by wave i % 4, V^T instruction i by wave
   // (i + 1) % 4 (3 / 3 / 2 / 2 per wave at d = 40).  Full tiles: uniform base (SGPR) + a per-lane byte offset that only
   // depends on the segment -- no per-tile address arithmetic on the VALU.
-  const int vwave = (wave + 3) & 3;                  // this wave issues V^T instructions vwave, vwave + 4
+  const int vwave = (wave + NW - 1) % NW;            // this wave issues V^T instructions vwave, vwave + NW
   unsigned koff[2][K_PER_WAVE], voff[2][V_PER_WAVE];
   int v_chunk[V_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < K_PER_WAVE; ++j) {
-    const int c = (wave + 4 * j) * 64 + lane;
+    const int c = (wave + NW * j) * 64 + lane;
     const int row = c / DCH, col = (c - row * DCH) * 8;
     koff[0][j] = (unsigned)(row * p.ldk[0] + col) * 2u;
     koff[1][j] = (unsigned)(row * p.ldk[1] + col) * 2u;
   }
 #pragma unroll
   for (int j = 0; j < V_PER_WAVE; ++j) {
-    const int row = (vwave + 4 * j) * 8 + (lane >> 3);
+    const int row = (vwave + NW * j) * 8 + (lane >> 3);
     v_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);
     voff[0][j] = (unsigned)(row * p.ldv[0] + v_chunk[j] * 8) * 2u;
     voff[1][j] = (unsigned)(row * p.ldv[1] + v_chunk[j] * 8) * 2u;
@@ -175,22 +181,22 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
       const char* base = kb + (size_t)kv0 * ldk * 2;
 #pragma unroll
       for (int j = 0; j < K_PER_WAVE; ++j)
-        if (wave + 4 * j < K_INST)
-          dma16_sv(base, seg ? koff[1][j] : koff[0][j], lds_addr(dst + (wave + 4 * j) * 512));
+        if (wave + NW * j < K_INST)
+          dma16_sv(base, seg ? koff[1][j] : koff[0][j], lds_addr(dst + (wave + NW * j) * 512));
     } else {                                         // tail tile: rows beyond n are clamped to the last valid key
 #pragma unroll
       for (int j = 0; j < K_PER_WAVE; ++j)
-        if (wave + 4 * j < K_INST) {
-          const int c = (wave + 4 * j) * 64 + lane;
+        if (wave + NW * j < K_INST) {
+          const int c = (wave + NW * j) * 64 + lane;
           const int row = c / DCH, col = (c - row * DCH) * 8;
           const int kr = min(kv0 + row, n - 1);
-          dma16_v(kb + ((size_t)kr * ldk + col) * 2, lds_addr(dst + (wave + 4 * j) * 512));
+          dma16_v(kb + ((size_t)kr * ldk + col) * 2, lds_addr(dst + (wave + NW * j) * 512));
         }
     }
   };
   // the ones-row group (rows D .. D+7 of the V^T image): row D = ones in the valid columns, zeros elsewhere
   auto issue_ones = [&](int stage, int nvalid) {
-    if (wave == 2) {
+    if (wave == NW / 2) {
       const int row = D + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const bool one = (row == D) && (chunk * 8 < nvalid);
@@ -208,16 +214,16 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
     if (kv0 + KVT <= n) {
 #pragma unroll
       for (int j = 0; j < V_PER_WAVE; ++j)
-        if (vwave + 4 * j < V_INST)
-          dma16_sv(base, seg ? voff[1][j] : voff[0][j], lds_addr(dst + (vwave + 4 * j) * 512));
+        if (vwave + NW * j < V_INST)
+          dma16_sv(base, seg ? voff[1][j] : voff[0][j], lds_addr(dst + (vwave + NW * j) * 512));
     } else {                                         // tail tile: 8-key chunks beyond n (n % 8 == 0) come from the zero page
 #pragma unroll
       for (int j = 0; j < V_PER_WAVE; ++j)
-        if (vwave + 4 * j < V_INST) {
+        if (vwave + NW * j < V_INST) {
           const bool valid = (kv0 + v_chunk[j] * 8) < n;
           const char* src = valid ? base + (seg ? voff[1][j] : voff[0][j])
                                   : reinterpret_cast<const char*>(idf_attn4_zero_page + (lane & 7) * 8);
-          dma16_v(src, lds_addr(dst + (vwave + 4 * j) * 512));
+          dma16_v(src, lds_addr(dst + (vwave + NW * j) * 512));
         }
     }
     // the ones row of this stage: restrict it for a tail tile, restore it when the stage last held a tail tile (tile t-VST)
@@ -360,9 +366,9 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   // 2 / 3 at d = 40) may stay in flight; everything older -- tile t+1's -- must be there.
   int n_mine = 0;                                    // LDS-DMA instructions this wave issues per full tile (wave-uniform)
 #pragma unroll
-  for (int j = 0; j < K_PER_WAVE; ++j) n_mine += (wave + 4 * j < K_INST) ? 1 : 0;
+  for (int j = 0; j < K_PER_WAVE; ++j) n_mine += (wave + NW * j < K_INST) ? 1 : 0;
 #pragma unroll
-  for (int j = 0; j < V_PER_WAVE; ++j) n_mine += (vwave + 4 * j < V_INST) ? 1 : 0;
+  for (int j = 0; j < V_PER_WAVE; ++j) n_mine += (vwave + NW * j < V_INST) ? 1 : 0;
   auto end_tile = [&](const bool counted) {
     if (VA == 2 && counted) {
       if (n_mine == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
     }
     if (exact_all) {                                // the abandoned pass may have left a tail-restricted ones row behind
       const unsigned short one = Elem<DT>::from_f32(1.0f);
-      for (int i = tid; i < VST * KVT; i += 256) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
+      for (int i = tid; i < VST * KVT; i += NT) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;
     }
     __syncthreads();                                // zero fill, ones row, ones fragment (or the abandoned pass) complete
     issue_k(0);
@@ -446,12 +452,12 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
         unsigned short* vdst = Vs + ((t + VA) % VST) * VSZ;
 #pragma unroll
         for (int j = 0; j < K_PER_WAVE; ++j)
-          if (wave + 4 * j < K_INST)
-            dma16_sv(kptr, koff[0][j], lds_addr(kdst + (wave + 4 * j) * 512));
+          if (wave + NW * j < K_INST)
+            dma16_sv(kptr, koff[0][j], lds_addr(kdst + (wave + NW * j) * 512));
 #pragma unroll
         for (int j = 0; j < V_PER_WAVE; ++j)
-          if (vwave + 4 * j < V_INST)
-            dma16_sv(vptr, voff[0][j], lds_addr(vdst + (vwave + 4 * j) * 512));
+          if (vwave + NW * j < V_INST)
+            dma16_sv(vptr, voff[0][j], lds_addr(vdst + (vwave + NW * j) * 512));
         kptr += kstep;
         vptr += KVT * 2;
         const unsigned acc = tile(FalseT{}, t);
@@ -486,7 +492,6 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   // barrier), so each wave transposes its 64 x D block through its own LDS slice and writes 16 B per lane with consecutive
   // lanes on consecutive chunks of a row: a wave store instruction covers whole 2*D-byte row segments.
   constexpr int sel = (D & 31) >> 3;
-  static_assert(4 * 64 * D <= 3 * KSZ + VST * VSZ, "the O staging block must fit the K / V^T rings");
   unsigned short* const ow = smem + wave * (64 * D);       // wave-private [64 queries][D]
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, in order, before its reads
   __builtin_amdgcn_wave_barrier();
   {
-    const int q0 = qb * 256 + wave * 64;
+    const int q0 = qb * NT + wave * 64;
     unsigned short* const obase = p.out + (size_t)b * p.sO + h * D;
 #pragma unroll
     for (int j = 0; j < DCH; ++j) {
@@ -523,11 +528,14 @@ __global__ __launch_bounds__(256, 2) void attn4_kernel(const AttnParams p, const
 
 template <int DT>
 int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
-  const int nqb = (p.nq + 255) / 256;
-  dim3 grid(nqb * p.H * B), block(256);
+  const int mode = idf_attn2_mode();
+  const int nw = mode == 1 ? 8 : 4;
+  const int nqb = (p.nq + nw * 64 - 1) / (nw * 64);
+  dim3 grid(nqb * p.H * B), block(nw * 64);
 #define IDF_ATTN4_CASE(KS, MT) \
   if (p.d == 8 * (2 * KS - 1)) { \
-    hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1>), grid, block, 0, s, p, nqb, idf_attn2_mode() == 2 ? 0 : 1); \
+    if (nw == 8) hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1, 8>), grid, block, 0, s, p, nqb, 1); \
+    else hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1, 4>), grid, block, 0, s, p, nqb, mode == 3 ? 0 : 1); \
     return idf_launch_status(); }
   IDF_ATTN4_CASE(2, 1)    // d = 24
   IDF_ATTN4_CASE(3, 2)    // d = 40

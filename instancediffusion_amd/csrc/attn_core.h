@@ -22,8 +22,11 @@ struct AttnParams {
 // 64-queries-per-wave LDS-DMA kernel for d in {24, 40, 56} (attention4.hip): max-free softmax with the reference value
 // folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid.  Returns IDF_ATTN2_UNSUPPORTED when the
 // shape does not qualify (the caller then runs the 32-queries-per-wave kernel of attention.hip).
-// Attention mode (idf_set_tuning(IDF_TUNE_ATTN2), env IDF_ATTN2): 0 = 32-query kernel only, 1 = this kernel when the shape
-// qualifies (default), 2 = the same with the plain block order (A/B of the XCD mapping).
+// Attention mode (idf_set_tuning(IDF_TUNE_ATTN2), env IDF_ATTN2): 0 = 32-query kernel only; 1 = this kernel when the shape
+// qualifies, as ONE 8-wave workgroup per 512 queries (default: every K / V^T tile is shared by eight waves -- 1.4 LDS-DMA
+// instructions per wave and tile instead of 2.75; +1.5 % bf16, +2-3 % fp16 and at 96^2, profiles/r03_attn_ab2_B64.log);
+// 2 = two 4-wave workgroups per CU (256 queries each; the round-2 geometry); 3 = mode 2 with the plain block order (A/B
+// of the XCD mapping).
 // The round-1 / round-2 variants this kernel replaced (attention2.hip: classic / lazy / software-pipelined online softmax;
 // attention5.hip: 8-wave ping-pong form) were measured slower and live under tools/ubench/archive/ with their logs in
 // profiles/r02_attn_*.

@@ -625,7 +625,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
     return prev;
   }
   if (knob == IDF_TUNE_ATTN2) {
-    if (value < 0 || value > 2) return IDF_E_ARG;
+    if (value < 0 || value > 3) return IDF_E_ARG;
     return idf_attn2_set_mode(value);
   }
   return IDF_E_ARG;

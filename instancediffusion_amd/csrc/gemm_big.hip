@@ -69,7 +69,11 @@ __device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigne
 // (q0 <-> q2, q1 <-> q3 between the lane halves) leave every lane with 16 CONSECUTIVE columns of its row:
 // n = a*32 + 16*hi + [0,16)  ->  two 16-B stores per (a, b), 16-B residual / rowbias loads, float4 bias loads.
 // LNS: the (mu, rstd) of the tile's A rows were computed in the K loop (lnm / lnr per 32-row fragment) instead of read.
-template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false>
+// STATS: by-product for a LayerNorm that follows (idf_gemm's out_stats) -- (mean, M2) of the 16-bit-ROUNDED values this wave
+// stores of each of its rows (BN/2 columns), accumulated around a per-lane pivot (no E[x^2] - mu^2 cancellation), the two
+// lane halves of a row merged with Chan's formula, one 8-B store per row and wave into p.stat_parts; a 16-B-per-row
+// finalize kernel replaces the pass that re-read the whole output (65 of them per forward in round 2).
+template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false, bool STATS = false>
 __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int slice, int tiles_n, int wm,
                                              int wn, int l31, int hi, float gate, const float* lnm = nullptr,
                                              const float* lnr = nullptr) {
@@ -163,6 +167,9 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
       });
     }
   } else {
+    float st_p[TM], st_s1[TM], st_s2[TM];                  // STATS: pivot, sum (x - p), sum (x - p)^2 per row fragment
+#pragma unroll
+    for (int b = 0; b < TM; ++b) { st_p[b] = 0.0f; st_s1[b] = 0.0f; st_s2[b] = 0.0f; }
     static_for<0, TN, 1>([&](auto AI) {
       constexpr int a = decltype(AI)::value;
       const int n = nw + a * 32 + 16 * hi;
@@ -233,11 +240,35 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + 4 * j) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
         } else {
           unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + n;
-          *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
-          *reinterpret_cast<u32x4*>(o + 8) = pack8<DT>(v + 8);
+          const u32x4 q0 = pack8<DT>(v), q1 = pack8<DT>(v + 8);
+          *reinterpret_cast<u32x4*>(o) = q0;
+          *reinterpret_cast<u32x4*>(o + 8) = q1;
+          if constexpr (STATS) {
+            float r[16];
+            unpack8<DT>(q0, r);
+            unpack8<DT>(q1, r + 8);
+            if (a == 0) st_p[b] = r[0];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float dlt = r[j] - st_p[b]; st_s1[b] += dlt; st_s2[b] = fmaf(dlt, dlt, st_s2[b]); }
+          }
         }
       }
     });
+    if constexpr (STATS) {
+      constexpr float cnt = 16.0f * TN;                      // values per lane and row: half of the wave's BN/2 columns
+      const int n_tile = (seq - m_tile * tiles_n);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const float mean = st_p[b] + st_s1[b] * (1.0f / cnt);
+        const float m2 = fmaxf(st_s2[b] - st_s1[b] * st_s1[b] * (1.0f / cnt), 0.0f);
+        const float mean_o = __shfl_xor(mean, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+        const float dlt = mean_o - mean;
+        const int m = mw + b * 32 + l31;
+        if (hi == 0 && m < p.M)
+          *reinterpret_cast<f32x2*>(p.stat_parts + ((size_t)m * p.parts + n_tile * 2 + wn) * 2) =
+              f32x2{0.5f * (mean + mean_o), m2 + m2_o + dlt * dlt * (0.5f * cnt)};
+      }
+    }
   }
 }
 
@@ -293,7 +324,7 @@ __device__ __forceinline__ void big_epilogue_vt(const CoreParams& p, f32x16 (&ac
 
 // Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
 //   <256, {320,256}, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages); <256, 128, 64, 3>: 3 x 48 KB stages.
-template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false>
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false, bool STATS = false>
 __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
   constexpr int WN = BN / 2, TN = WN / 32;
   constexpr int NW = BM / 32;                              // waves per workgroup (8 or 4)
@@ -533,7 +564,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, p.ln_stats, 0);
       }
     } else {
-      big_epilogue<DT, BM, BN, TN, SPLIT, LNS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
+      big_epilogue<DT, BM, BN, TN, SPLIT, LNS, STATS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
     }
   };
 
@@ -559,16 +590,16 @@ int num_cu() {
   return g_num_cu;
 }
 
-template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false>
+template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false, bool STATS = false>
 int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   constexpr int BM = 256, BKT = 64;
-  if constexpr (!SPLIT && !LNS && !VT && NSTG == 2) {
+  if constexpr (!SPLIT && !LNS && !VT && !STATS && NSTG == 2) {
     if (splitk > 1) return launch_big_cfg<DT, BN, NSTG, CONV, true>(p, s, splitk);
   }
-  if constexpr (!SPLIT && !LNS && !CONV && NSTG == 2) {
+  if constexpr (!SPLIT && !LNS && !CONV && !STATS && NSTG == 2) {
     if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT>(p, s, 1);
   }
-  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT>;
+  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS>;
   constexpr int smem = NSTG * (BM + BN) * BKT * 2 + ((VT && LNS) ? 8 * 128 * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
@@ -590,8 +621,9 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
 std::atomic<long long> idf_stat_big_launches{0};
 
 // Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
-int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out) {
+int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out, int* parts_out) {
   if (splitk_out) *splitk_out = 1;
+  if (parts_out) *parts_out = 0;
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
   if (p.K < 2 * BK || (p.K % BK) != 0) return IDF_BIG_UNSUPPORTED;
   if (p.epi & IDF_EPI_OUT_NCHW) return IDF_BIG_UNSUPPORTED;
@@ -644,7 +676,14 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
     if (rows * (unsigned long long)p.lda >= (1ull << 31) || (unsigned long long)p.N * p.ldw >= (1ull << 31)) return IDF_BIG_UNSUPPORTED;
   }
   ++idf_stat_big_launches;
+  // output-row statistics from the epilogue registers: unsplit dense 16-bit-output GEMMs whose epilogue is the plain one
+  const bool stats = parts_out && p.stat_parts && !conv && !geglu && !vt && !self_ln && splitk == 1 && bn != 128 &&
+                     !(p.epi & IDF_EPI_OUT_F32) && (((uintptr_t)p.stat_parts) & 7u) == 0;
+  CoreParams ps = p;
+  if (stats) { ps.parts = 2 * (p.N / bn); *parts_out = ps.parts; }
 #define IDF_BIG_DISPATCH(DT)                                                                                              \
+  if (stats) return bn == 320 ? launch_big_cfg<DT, 320, 2, false, false, false, false, true>(ps, s)                        \
+                              : launch_big_cfg<DT, 256, 2, false, false, false, false, true>(ps, s);                       \
   if (vt) return launch_big_cfg<DT, 320, 2, false, false, false, true>(p, s);                                             \
   if (bn == 128) {                       /* 128-wide tiles (the VAE's 128-channel convs at 512^2): 3 stages of 48 KB */  \
     if (conv) return launch_big_cfg<DT, 128, 3, true>(p, s);                                                              \

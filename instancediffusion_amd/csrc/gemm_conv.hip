@@ -573,7 +573,7 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
 }
 
 template <int DT, bool CONV>
-int launch(const CoreParams& p, int batch, hipStream_t s) {
+int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullptr) {
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
   // tile choice: 128x128 when N fills it; 128(M) x 64(N) for N = 64 mod 128 (e.g. 320) or small N.  For the conv
   // (long K = 9*Cin) the denser 64x64 wave tile wins even with a half-empty last column tile at Cout = 320
@@ -587,7 +587,7 @@ int launch(const CoreParams& p, int batch, hipStream_t s) {
   const int big = gemm_big_mode();
   if (big > 0 && batch == 1) {
     int splitk = 1;
-    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk);
+    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out);
     if (rc != IDF_BIG_UNSUPPORTED) {
       if (rc == 0 && splitk > 1) {
         CoreParams q = p;
@@ -616,6 +616,31 @@ int launch(const CoreParams& p, int batch, hipStream_t s) {
 }
 
 }  // namespace
+
+// out_stats finalize: (mu, rstd) of a row from the `parts` equal-count (mean, M2) slots the persistent kernel's epilogue left
+// (Chan's pairwise update, slots merged in index order: bitwise reproducible)
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ parts, int P, float cols, float* __restrict__ out,
+                                                            int M, float eps) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const f32x2* pp = reinterpret_cast<const f32x2*>(parts) + (size_t)m * P;
+  f32x2 t = pp[0];
+  float mean = t[0], m2 = t[1], n = cols;
+  for (int i = 1; i < P; ++i) {
+    t = pp[i];
+    const float dlt = t[0] - mean, nn = n + cols;
+    mean += dlt * (cols / nn);
+    m2 += t[1] + dlt * dlt * (n * cols / nn);
+    n = nn;
+  }
+  reinterpret_cast<f32x2*>(out)[m] = f32x2{mean, rsqrtf(m2 / n + eps)};
+}
+
+int idf_stats_finalize(const float* stat_parts, int parts, int cols_per_part, float* out_stats, int M, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stat_parts, parts, (float)cols_per_part,
+                     out_stats, M, eps);
+  return idf_launch_status();
+}
 
 extern "C" int idf_set_tuning(int knob, int value) {
   if (knob == IDF_TUNE_GEMM_BIG) {
@@ -716,10 +741,17 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
     if (a->dtype == IDF_F16) return launch<IDF_F16, false>(p2, 1, s);
     return IDF_E_UNSUPPORTED;
   }
-  if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p, batch, s);
-  else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p, batch, s);
-  if (rc == 0 && a->out_stats)
-    rc = idf_row_stats(a->out, a->ldo, a->out_stats, batch * a->M, a->N, a->out_stats_eps, a->dtype, stream);
+  // out_stats: the persistent kernel leaves per-wave (mean, M2) partials of its output rows in the head of the workspace
+  // (when it takes the launch, unsplit) and a 16-B-per-row finalize pass merges them; otherwise the statistics pass re-reads
+  // the output as before
+  int parts = 0;
+  if (a->out_stats && batch == 1 && p.ws && p.ws_bytes >= (size_t)a->M * 32 * sizeof(float)) p.stat_parts = p.ws;
+  if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p, batch, s, &parts);
+  else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p, batch, s, &parts);
+  if (rc == 0 && a->out_stats) {
+    if (parts > 0) rc = idf_stats_finalize(p.stat_parts, parts, a->N / parts, a->out_stats, a->M, a->out_stats_eps, s);
+    else rc = idf_row_stats(a->out, a->ldo, a->out_stats, batch * a->M, a->N, a->out_stats_eps, a->dtype, stream);
+  }
   return rc;
 }
 

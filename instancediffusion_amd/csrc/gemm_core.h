@@ -23,6 +23,9 @@ struct CoreParams {
   float ln_eps; float* ln_stats_out;
   // fused q | k | v projection: output columns n >= vt_col0 are stored transposed, vt_out[(n - vt_col0) * ld_vt + m]
   unsigned short* vt_out; int ld_vt; int vt_col0;
+  // out_stats by-product of the persistent kernel: every wave leaves (mean, M2) of the BN/2 output columns it owns of a row
+  // in stat_parts[(m * parts + tile_n * 2 + wn) * 2 ..] (fp32, workspace); stats_finalize merges the `parts` slots of a row
+  float* stat_parts; int parts;
 };
 
 constexpr int BK = 64;
@@ -122,4 +125,9 @@ __device__ __forceinline__ void epilogue8(const CoreParams& p, int bz, int m, in
 #define IDF_BIG_UNSUPPORTED (-100)
 extern std::atomic<long long> idf_stat_big_launches;     // process-global launch counter (idf_get_stat)
 // *splitk_out > 1 on return: the kernel left fp32 partials of that many K-slices in p.ws; the caller runs the reducer
-int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out);
+// *parts_out (optional): > 0 when the kernel left per-wave partial output-row statistics in p.stat_parts (p.stat_parts
+// offered and the launch was an unsplit dense GEMM), the number of slots per row.
+int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out,
+                   int* parts_out = nullptr);
+// (mu, rstd) per row from `parts` equal-count (mean, M2) slots per row (fixed merge order): out_stats[m] = f32x2
+int idf_stats_finalize(const float* stat_parts, int parts, int cols_per_part, float* out_stats, int M, float eps, hipStream_t s);

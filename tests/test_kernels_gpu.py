@@ -739,6 +739,26 @@ def test_gemm_layernorm_self_stats(ops, M, N, K, geglu):
     assert mu_err < 1e-4 and rs_rel < 1e-4
 
 
+@pytest.mark.parametrize("ratio", [10.0, 100.0])
+def test_gemm_layernorm_self_stats_large_mean_bound(ops, ratio):
+    """the in-loop row sums of the persistent kernel are single-pass (sum x, sum x^2 by v_dot2c, fp32), so a row
+    with |mean| / std = r loses about r^2 * 2^-24 * sqrt(K) of its variance to cancellation -- gfx950 has no packed bf16
+    subtract to shift the operands first.  Stated bound, checked here against the exact two-pass idf_row_stats: rstd relative
+    error <= 2e-6 * r^2 (r = 10: 2e-4, r = 100: 2e-2; LayerNorm inputs of this model have r < 10).  The engine only uses the
+    in-loop sums at C = 320 (LN_SELF mode 1); idf_row_stats / the epilogue partials (shifted, Chan-merged) have no such term."""
+    M, N, K = 65536, 640, 320
+    x = to16(gen((M, K), 93) + ratio)
+    w16 = to16(gen((N, K), 95, K ** -0.5))
+    st_self, st_exact = ops.empty((M, 2), torch.float32), ops.empty((M, 2), torch.float32)
+    ops.gemm(dev(x), dev(w16), ops.empty((M, N)), bias=dev(gen((N,), 96)), ln_row=(None, dev(w16.float().sum(1))), ln_stats_out=st_self)
+    ops.row_stats(dev(x), st_exact, 1e-5)
+    torch.cuda.synchronize()
+    rs = float((st_self[:, 1] / st_exact[:, 1] - 1).abs().max())
+    mu = float((st_self[:, 0] - st_exact[:, 0]).abs().max())
+    print(f"[bound] in-loop LayerNorm sums at |mean|/std = {ratio:g}: rstd rel err {rs:.2e} (bound {2e-6 * ratio ** 2:.1e}), mu abs err {mu:.2e}")
+    assert rs <= 2e-6 * ratio ** 2 and mu < 1e-4 * ratio
+
+
 def test_gemm_layernorm_self_stats_f16():
     """The fp16 instantiation of the in-loop row sums (v_dot2c_f32_f16) on the persistent kernel."""
     import torch.nn.functional as F
@@ -828,6 +848,33 @@ def test_gemm_fused_qkv_f16_and_argument_checks():
         o16.gemm(dev(ai), dev(wi), qk, vt_out=vt, act="silu")
     with pytest.raises(_lib.IdfError):
         o16.gemm(dev(ai), dev(wi), qk, vt_out=vt, res=qk)
+
+
+@pytest.mark.parametrize("M,N,K,offset", [(65536, 320, 320, 0.0), (65536 + 48, 320, 320, 40.0), (32768, 640, 640, 0.0),
+                                          (16384, 1280, 1280, 5.0), (65536, 512, 128, 0.0)])
+def test_gemm_out_stats_from_the_epilogue(ops, M, N, K, offset):
+    """Bench-sized producers: the persistent kernel leaves per-wave (mean, M2) partials of the rows it stores and a 16-B-per-row
+    finalize pass merges them (2, 4, 8 slots per row at N = 320 / 640 / 1280; 256-wide tiles at N = 512) -- no pass re-reads
+    the output.  The result must equal the exact two-pass statistics of the 16-bit output actually written, also for rows
+    whose |mean| is hundreds of standard deviations (shifted accumulation + Chan merge: no E[x^2] - mu^2)."""
+    from instancediffusion_amd import _lib
+    lib = _lib.load()
+    a, w, b = to16(gen((M, K), 86)), to16(gen((N, K), 87, K ** -0.5)), gen((N,), 88) + offset
+    r = to16(gen((M, N), 89) * 0.1 + offset)
+    st = ops.empty((M, 2), torch.float32)
+    y = dev(r).clone()
+    prev = lib.idf_set_tuning(0, 2)            # whenever the shape qualifies (M = 65584 is 257 tiles: the auto rule would decline)
+    start = lib.idf_get_stat(0)
+    ops.gemm(dev(a), dev(w), y, bias=dev(b), res=y, out_stats=st, out_stats_eps=1e-5)
+    torch.cuda.synchronize()
+    lib.idf_set_tuning(0, prev)
+    assert lib.idf_get_stat(0) - start == 1, "bench-sized producer must run on the persistent kernel"
+    yf = y.float().cpu()
+    mu, rs = yf.double().mean(-1), torch.rsqrt(yf.double().var(-1, unbiased=False) + 1e-5)
+    mu_err = float((st[:, 0].cpu().double() - mu).abs().max() / (mu.abs().max() + 1e-6))
+    rs_err = float((st[:, 1].cpu().double() / rs - 1).abs().max())
+    print(f"[parity] out_stats from the epilogue M{M} N{N} K{K} offset {offset}: mu rel err {mu_err:.2e}, rstd rel err {rs_err:.2e}")
+    assert mu_err < 2e-6 and rs_err < 2e-4
 
 
 def test_gemm_out_stats(ops):

@@ -149,83 +149,75 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
   // (i + 1) % 4 (3 / 3 / 2 / 2 per wave at d = 40).  Full tiles: uniform base (SGPR) + a per-lane byte offset that only
   // depends on the segment -- no per-tile address arithmetic on the VALU.
   const int vwave = (wave + NW - 1) % NW;            // this wave issues V^T instructions vwave, vwave + NW
-  unsigned koff[2][K_PER_WAVE], voff[2][V_PER_WAVE];
-  int v_chunk[V_PER_WAVE];
+  // Only the segment-0 full-tile offsets of the steady-state loop are kept in registers.  Everything the other tiles need
+  // (first tiles, segment change, tails, the ones row) is RECOMPUTED inside issue_k / issue_v from an opaque copy of the lane
+  // id: left to the compiler, those address computations were hoisted out of the loops and kept alive across the hot loop
+  // -- 72 spilled VGPRs, i.e. 288 B of scratch per lane written by every wave's prologue: 600 MB per launch at batch 64,
+  // which was the "4.6x write amplification" of profiles/r02_rocprof/pmc_traffic_b64.json (not the store width).
+  unsigned koff0[K_PER_WAVE], voff0[V_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < K_PER_WAVE; ++j) {
     const int c = (wave + NW * j) * 64 + lane;
     const int row = c / DCH, col = (c - row * DCH) * 8;
-    koff[0][j] = (unsigned)(row * p.ldk[0] + col) * 2u;
-    koff[1][j] = (unsigned)(row * p.ldk[1] + col) * 2u;
+    koff0[j] = (unsigned)(row * p.ldk[0] + col) * 2u;
   }
 #pragma unroll
   for (int j = 0; j < V_PER_WAVE; ++j) {
     const int row = (vwave + NW * j) * 8 + (lane >> 3);
-    v_chunk[j] = (lane & 7) ^ ((row >> 1) & 7);
-    voff[0][j] = (unsigned)(row * p.ldv[0] + v_chunk[j] * 8) * 2u;
-    voff[1][j] = (unsigned)(row * p.ldv[1] + v_chunk[j] * 8) * 2u;
+    voff0[j] = (unsigned)(row * p.ldv[0] + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u;
   }
-  const char* const kbase0 = reinterpret_cast<const char*>(p.k[0] + (size_t)b * p.sK[0] + h * D);
-  const char* const kbase1 = reinterpret_cast<const char*>(p.k[1] + (size_t)b * p.sK[1] + h * D);
-  const char* const vbase0 = reinterpret_cast<const char*>(p.vt[0] + (size_t)b * p.sV[0] + (size_t)(h * D) * p.ldv[0]);
-  const char* const vbase1 = reinterpret_cast<const char*>(p.vt[1] + (size_t)b * p.sV[1] + (size_t)(h * D) * p.ldv[1]);
+  auto cold_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
 
   auto issue_k = [&](int t) {
+    const int ln = cold_lane();
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
     const int ldk = p.ldk[seg];
-    const char* kb = seg ? kbase1 : kbase0;
+    const char* kb = reinterpret_cast<const char*>(p.k[seg] + (size_t)b * p.sK[seg] + h * D);
     unsigned short* dst = Ks + (t % 3) * KSZ;
-    if (kv0 + KVT <= n) {
-      const char* base = kb + (size_t)kv0 * ldk * 2;
+    const bool full = kv0 + KVT <= n;
 #pragma unroll
-      for (int j = 0; j < K_PER_WAVE; ++j)
-        if (wave + NW * j < K_INST)
-          dma16_sv(base, seg ? koff[1][j] : koff[0][j], lds_addr(dst + (wave + NW * j) * 512));
-    } else {                                         // tail tile: rows beyond n are clamped to the last valid key
-#pragma unroll
-      for (int j = 0; j < K_PER_WAVE; ++j)
-        if (wave + NW * j < K_INST) {
-          const int c = (wave + NW * j) * 64 + lane;
-          const int row = c / DCH, col = (c - row * DCH) * 8;
-          const int kr = min(kv0 + row, n - 1);
-          dma16_v(kb + ((size_t)kr * ldk + col) * 2, lds_addr(dst + (wave + NW * j) * 512));
-        }
-    }
+    for (int j = 0; j < K_PER_WAVE; ++j)
+      if (wave + NW * j < K_INST) {
+        const int c = (wave + NW * j) * 64 + ln;
+        const int row = c / DCH, col = (c - row * DCH) * 8;
+        // tail tile: rows beyond n are clamped to the last valid key
+        const int kr = full ? kv0 + row : min(kv0 + row, n - 1);
+        dma16_v(kb + ((size_t)kr * ldk + col) * 2, lds_addr(dst + (wave + NW * j) * 512));
+      }
   };
   // the ones-row group (rows D .. D+7 of the V^T image): row D = ones in the valid columns, zeros elsewhere
   auto issue_ones = [&](int stage, int nvalid) {
     if (wave == NW / 2) {
-      const int row = D + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int ln = cold_lane();
+      const int row = D + (ln >> 3);
+      const int chunk = (ln & 7) ^ ((row >> 1) & 7);
       const bool one = (row == D) && (chunk * 8 < nvalid);
-      const unsigned short* src = one ? idf_attn4_ones_page[DT == IDF_BF16 ? 0 : 1] : idf_attn4_zero_page + (lane & 7) * 8;
+      const unsigned short* src = one ? idf_attn4_ones_page[DT == IDF_BF16 ? 0 : 1] : idf_attn4_zero_page + (ln & 7) * 8;
       dma16_v(src, lds_addr(Vs + stage * VSZ + V_INST * 512));
     }
   };
   auto issue_v = [&](int t) {
+    const int ln = cold_lane();
     const int seg = (t < T0) ? 0 : 1;
     const int kv0 = (seg ? (t - T0) : t) * KVT;
     const int n = p.n[seg];
-    const char* vb = seg ? vbase1 : vbase0;
+    const int ldv = p.ldv[seg];
+    const char* vb = reinterpret_cast<const char*>(p.vt[seg] + (size_t)b * p.sV[seg] + (size_t)(h * D) * ldv);
     unsigned short* dst = Vs + (t % VST) * VSZ;
     const char* base = vb + (size_t)kv0 * 2;
-    if (kv0 + KVT <= n) {
 #pragma unroll
-      for (int j = 0; j < V_PER_WAVE; ++j)
-        if (vwave + NW * j < V_INST)
-          dma16_sv(base, seg ? voff[1][j] : voff[0][j], lds_addr(dst + (vwave + NW * j) * 512));
-    } else {                                         // tail tile: 8-key chunks beyond n (n % 8 == 0) come from the zero page
-#pragma unroll
-      for (int j = 0; j < V_PER_WAVE; ++j)
-        if (vwave + NW * j < V_INST) {
-          const bool valid = (kv0 + v_chunk[j] * 8) < n;
-          const char* src = valid ? base + (seg ? voff[1][j] : voff[0][j])
-                                  : reinterpret_cast<const char*>(idf_attn4_zero_page + (lane & 7) * 8);
-          dma16_v(src, lds_addr(dst + (vwave + NW * j) * 512));
-        }
-    }
+    for (int j = 0; j < V_PER_WAVE; ++j)
+      if (vwave + NW * j < V_INST) {
+        const int row = (vwave + NW * j) * 8 + (ln >> 3);
+        const int chunk = (ln & 7) ^ ((row >> 1) & 7);
+        // tail tile: 8-key chunks beyond n (n % 8 == 0) come from the zero page
+        const bool valid = (kv0 + chunk * 8) < n;
+        const char* src = valid ? base + ((size_t)row * ldv + chunk * 8) * 2
+                                : reinterpret_cast<const char*>(idf_attn4_zero_page + (ln & 7) * 8);
+        dma16_v(src, lds_addr(dst + (vwave + NW * j) * 512));
+      }
     // the ones row of this stage: restrict it for a tail tile, restore it when the stage last held a tail tile (tile t-VST)
     const bool tail = (kv0 + KVT > n);
     bool prev_tail = false;
@@ -247,6 +239,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
   const int vfoff = l31 * KVT;                      // V^T fragment row offset
 
   auto load_kf = [&](u32x4 (&dst)[2][NKS], int stage) {
+    // `hi` through an opaque copy: the hi ? ones_frag : row select below is then made per call (2 v_cndmask per tile) instead
+    // of being hoisted as six per-stage address registers that live across the whole kernel (and were spilled)
+    int hi_o = hi;
+    asm volatile("" : "+v"(hi_o));
     const unsigned short* Kc = Ks + stage * KSZ;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -254,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
 #pragma unroll
       for (int ks = 0; ks < NKS - 1; ++ks) dst[st][ks] = *reinterpret_cast<const u32x4*>(base + ks * 16);
       // last K-step: hi = 0 lanes read elements 16*(NKS-1) .. +7 of the row, hi = 1 lanes the constant {1, 0, .., 0}
-      const unsigned short* last = hi ? ones_frag : base + (NKS - 1) * 16;
+      const unsigned short* last = hi_o ? ones_frag : base + (NKS - 1) * 16;
       dst[st][NKS - 1] = *reinterpret_cast<const u32x4*>(last);
     }
   };
@@ -443,8 +439,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
     int t = 1;
     if (!exact_all) {
       // ---- steady state: the loads issued here (K(t+2), V^T(t+VA)) are full tiles of segment 0: running scalar bases
-      const char* kptr = kbase0 + (size_t)3 * KVT * p.ldk[0] * 2;
-      const char* vptr = vbase0 + (size_t)(1 + VA) * KVT * 2;
+      const char* kptr = reinterpret_cast<const char*>(p.k[0] + (size_t)b * p.sK[0] + h * D) + (size_t)3 * KVT * p.ldk[0] * 2;
+      const char* vptr = reinterpret_cast<const char*>(p.vt[0] + (size_t)b * p.sV[0] + (size_t)(h * D) * p.ldv[0]) + (size_t)(1 + VA) * KVT * 2;
       const size_t kstep = (size_t)KVT * p.ldk[0] * 2;
       for (; t + 2 < F0; ++t) {
         // Every wave passed the barrier that ended tile t-1: K(t+1) and V^T(t) are visible, K(t-1) / V^T(t-1) are dead.
@@ -453,11 +449,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
 #pragma unroll
         for (int j = 0; j < K_PER_WAVE; ++j)
           if (wave + NW * j < K_INST)
-            dma16_sv(kptr, koff[0][j], lds_addr(kdst + (wave + NW * j) * 512));
+            dma16_sv(kptr, koff0[j], lds_addr(kdst + (wave + NW * j) * 512));
 #pragma unroll
         for (int j = 0; j < V_PER_WAVE; ++j)
           if (vwave + NW * j < V_INST)
-            dma16_sv(vptr, voff[0][j], lds_addr(vdst + (vwave + NW * j) * 512));
+            dma16_sv(vptr, voff0[j], lds_addr(vdst + (vwave + NW * j) * 512));
         kptr += kstep;
         vptr += KVT * 2;
         const unsigned acc = tile(FalseT{}, t);

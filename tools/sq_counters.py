@@ -2,7 +2,15 @@
 into one per-kernel table: average counter value per dispatch, plus derived ratios for the attention claims
 (MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES-equivalent), wait fractions of SQ_WAVE_CYCLES).
 
-    python tools/sq_counters.py <out_csv> <pass_dir> [<pass_dir> ...] [--match attn]
+    python tools/sq_counters.py <out_csv> <pass_dir> [<pass_dir> ...] [--match attn] [--useful 0.714]
+
+Normalised matrix-pipe numbers (the old `mfma_busy_over_sq_busy` was a ratio of two unnormalised sums):
+  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)   -- SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed
+      over the chip's SIMDs (32 per 32x32x16 bf16 MFMA, MI355X_MICROARCH.md); kernel cycles = GRBM_GUI_ACTIVE of the dispatch
+      when that counter was collected in a pass, else duration_ns x 2.1 GHz (flagged in `cycles_source`);
+  useful_frac = mfma_busy_frac x --useful (the share of the issued MFMA work that is algorithmic: d = 40 attention pads
+      Q.K^T 40 -> 48 and P.V 40 -> 64, 640 useful of 896 issued cycles = 0.714) -- comparable with the timing-derived
+      fraction of the 2.5 PFLOP/s peak.
 """
 import csv
 import glob
@@ -14,9 +22,13 @@ from collections import defaultdict
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     match = None
+    useful = None
     if "--match" in sys.argv:
         match = sys.argv[sys.argv.index("--match") + 1]
         args = [a for a in args if a != match]
+    if "--useful" in sys.argv:
+        useful = float(sys.argv[sys.argv.index("--useful") + 1])
+        args = [a for a in args if a != sys.argv[sys.argv.index("--useful") + 1]]
     out_csv, dirs = args[0], args[1:]
     tot = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
@@ -43,8 +55,15 @@ def main():
                       "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC"):
                 if c in avg:
                     row["frac_" + c[3:].lower() + "_of_wave_cycles"] = round(avg[c] / wc, 4)
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "SQ_BUSY_CYCLES" in avg and avg["SQ_BUSY_CYCLES"]:
-            row["mfma_busy_over_sq_busy"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / avg["SQ_BUSY_CYCLES"], 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
+            n_simd = 1024                                    # 256 CUs x 4 SIMDs
+            if avg.get("GRBM_GUI_ACTIVE"):
+                cycles, row["cycles_source"] = avg["GRBM_GUI_ACTIVE"], "GRBM_GUI_ACTIVE"
+            else:
+                cycles, row["cycles_source"] = row["avg_ns_under_profiler"] * 2.1, "duration_ns x 2.1 GHz (assumed clock)"
+            row["mfma_busy_frac"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (n_simd * cycles), 4)
+            if useful is not None:
+                row["useful_frac"] = round(row["mfma_busy_frac"] * useful, 4)
         rows.append(row)
     keys = []
     for r in rows:

@@ -238,11 +238,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
   const int kfoff = kperm * D + hi * 8;             // element offset of the lane's K fragment inside a 32-key half
   const int vfoff = l31 * KVT;                      // V^T fragment row offset
 
-  auto load_kf = [&](u32x4 (&dst)[2][NKS], int stage) {
-    // `hi` through an opaque copy: the hi ? ones_frag : row select below is then made per call (2 v_cndmask per tile) instead
-    // of being hoisted as six per-stage address registers that live across the whole kernel (and were spilled)
-    int hi_o = hi;
-    asm volatile("" : "+v"(hi_o));
+  // `hi_o`: an opaque copy of `hi` (made once per tile, in front of its MFMAs): the hi ? ones_frag : row select below is then
+  // made per call (2 v_cndmask per tile) instead of being hoisted as six per-stage address registers that live across the
+  // whole kernel (and were spilled)
+  auto load_kf = [&](u32x4 (&dst)[2][NKS], int stage, int hi_o) {
     const unsigned short* Kc = Ks + stage * KSZ;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -338,6 +337,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
   // common path: no max, no branch between the K.Q^T MFMAs and the last P.V MFMA; returns the OR of all packed P words.
   auto tile = [&](auto exact_tag, const int t) -> unsigned {
     constexpr bool EXACT = decltype(exact_tag)::value;
+    int hi_o = hi;
+    asm volatile("" : "+v"(hi_o));
     qk(0);
     qk(1);
     if constexpr (EXACT) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
     unsigned acc = exp_pack(0);
     pv(0, t % VST);
     acc |= exp_pack(1);
-    load_kf(kf, (t + 1) % 3);                        // next tile's K fragments (a stale stage after the last tile: unused)
+    load_kf(kf, (t + 1) % 3, hi_o);                  // next tile's K fragments (a stale stage after the last tile: unused)
     pv(1, t % VST);
 #pragma unroll
     for (int st = 0; st < 2; ++st)
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
     if (VA == 2 && T > 1) issue_v(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    load_kf(kf, 0);
+    load_kf(kf, 0, hi);
 
     // ---- tile 0: exact (fixes the reference value m of every query)
     if (T > 2) issue_k(2);

@@ -57,8 +57,8 @@ const char* idf_build_info(void);
  *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default (1).
  *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; 1 = when the shape qualifies
  *   (d in {24,40,56}, n0 % 8 == n1 % 8 == 0, no mask) the 64-queries-per-wave LDS-DMA kernel (attention4.hip: max-free
- *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid) as one
- *   8-wave workgroup per 512 queries; 2 = the same kernel as two 4-wave workgroups per CU (256 queries each); 3 = mode 2
+ *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid) as two
+ *   4-wave workgroups per CU (256 queries each); 2 = the same kernel as one 8-wave workgroup per 512 queries; 3 = mode 1
  *   with the plain block order (A/B of the XCD mapping).  Initial value: env IDF_ATTN2 or the default (1).
  * (ABI 2 also exposed the kernel variants that were measured slower -- GEMM geometries 1..6, attention modes 1..14; they
  * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.) */

@@ -70,7 +70,8 @@ template <> struct RefShift<IDF_F16> { static constexpr float v = 1.0f; };     /
 // NW = waves per workgroup (64 queries each).  4: two independent workgroups per CU (their phases drift apart, which overlaps
 // one's MFMAs with the other's exponentials).  8: ONE workgroup per CU sharing every K / V^T tile among twice as many waves --
 // an LDS-DMA instruction holds its issuing wave ~180+ cycles (tools/ubench/dma_rate.hip), and with 11 KB per tile that is
-// 2.75 instructions per wave and tile at NW = 4, 1.4 at NW = 8 (the default since round 3; A/B: profiles/r03_attn_ab2_B64.log).
+// 2.75 instructions per wave and tile at NW = 4, 1.4 at NW = 8 (mode 2: +1 % in isolation, -3 % inside the forward; NW = 4 stays
+// the default -- profiles/r03_attn_ab*_B64.log, r03_shape_profile_B64_attn{1,2}.log).
 template <int DT, int NKS, int NMT, int VA, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, const int nqb, const int xcd_order) {
   constexpr int DCH = 2 * NKS - 1;                 // 16-B chunks per K row
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
 template <int DT>
 int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
   const int mode = idf_attn2_mode();
-  const int nw = mode == 1 ? 8 : 4;
+  const int nw = mode == 2 ? 8 : 4;
   const int nqb = (p.nq + nw * 64 - 1) / (nw * 64);
   dim3 grid(nqb * p.H * B), block(nw * 64);
 #define IDF_ATTN4_CASE(KS, MT) \

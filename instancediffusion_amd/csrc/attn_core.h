@@ -23,10 +23,10 @@ struct AttnParams {
 // folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid.  Returns IDF_ATTN2_UNSUPPORTED when the
 // shape does not qualify (the caller then runs the 32-queries-per-wave kernel of attention.hip).
 // Attention mode (idf_set_tuning(IDF_TUNE_ATTN2), env IDF_ATTN2): 0 = 32-query kernel only; 1 = this kernel when the shape
-// qualifies, as ONE 8-wave workgroup per 512 queries (default: every K / V^T tile is shared by eight waves -- 1.4 LDS-DMA
-// instructions per wave and tile instead of 2.75; +1.5 % bf16, +2-3 % fp16 and at 96^2, profiles/r03_attn_ab2_B64.log);
-// 2 = two 4-wave workgroups per CU (256 queries each; the round-2 geometry); 3 = mode 2 with the plain block order (A/B
-// of the XCD mapping).
+// qualifies, as two 4-wave workgroups per CU (256 queries each; default); 2 = as ONE 8-wave workgroup per 512 queries (every
+// K / V^T tile shared by eight waves: 1.4 LDS-DMA instructions per wave and tile instead of 2.75 -- +1 % in isolation,
+// -3 % inside the forward, where the two independent workgroups of a CU overlap better: profiles/r03_attn_ab*_B64.log,
+// r03_shape_profile_B64_attn{1,2}.log); 3 = mode 1 with the plain block order (A/B of the XCD mapping).
 // The round-1 / round-2 variants this kernel replaced (attention2.hip: classic / lazy / software-pipelined online softmax;
 // attention5.hip: 8-wave ping-pong form) were measured slower and live under tools/ubench/archive/ with their logs in
 // profiles/r02_attn_*.

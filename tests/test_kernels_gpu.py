@@ -573,7 +573,7 @@ def test_big_kernel_split_k(ops, ref):
 # ---------------------------------------------------------------------------------------------------
 # the 64-queries-per-wave attention kernel (attention4.hip), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3], ids=["v4-8waves", "v4-4waves", "v4-4waves-plain-grid"])
+@pytest.fixture(params=[1, 2, 3], ids=["v4-4waves", "v4-8waves", "v4-4waves-plain-grid"])
 def attn2(request):
     """The 64-queries-per-wave LDS-DMA kernel (attention4.hip) in its two block orders; yields its launch counter."""
     from instancediffusion_amd import _lib

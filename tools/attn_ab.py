@@ -1,7 +1,8 @@
 """A/B of the attention kernels on the headline shapes (MI355X box): python tools/attn_ab.py [batch=64] [modes=1,2,0]
 Prints TFLOP/s per (shape, mode); mode = IDF_TUNE_ATTN2 value (0 = 32-query kernel only, 1 = 64-query LDS-DMA kernel for d = 40 as
-8-wave workgroups (default), 2 = as 4-wave workgroups, 3 = 4-wave + plain block order).  d = 80 / 160 / cross-attention always
-run the 32-query kernel.  (profiles/r03_attn_ab2_B64.log was taken before the renumbering: its mode 3 is today's mode 1.)"""
+4-wave workgroups (default), 2 = as 8-wave workgroups, 3 = 4-wave + plain block order).  d = 80 / 160 / cross-attention always
+run the 32-query kernel.  (Mode numbers of the committed logs: r03_attn_ab1: 1 = 4-wave, 2 = plain order; r03_attn_ab2: 1 = 4-wave,
+3 = 8-wave; r03_attn_ab3: 1 = 8-wave, 2 = 4-wave.)"""
 import json
 import os
 import sys

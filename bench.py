@@ -252,8 +252,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images-per-gpu", type=int, default=32)  # 32 images x (8+1) trajectories x cond/uncond = 9 forwards of 64 rows per MIS step
-    ap.add_argument("--max-units", type=int, default=32, help="MIS phase-1 (instance, image) units per batched forward")
+    ap.add_argument("--images-per-gpu", type=int, default=32)  # 32 images x (8+1) trajectories = 288 units per MIS step
+    ap.add_argument("--max-units", type=int, default=64,
+                    help="MIS phase-1 (instance, image) units per batched forward: 64 units x cond/uncond = 128-row forwards (4 of them + one "
+                         "64-row forward per MIS step at 32 images; 1.42 ms per row against 1.47 at 64 rows, "
+                         "profiles/r03_bench_width_ab.json); phase 2 runs 64-row forwards (one row pair per image)")
     ap.add_argument("--images-total", type=int, default=0,
                     help="strong scaling: fix the GLOBAL images per step (split over the ranks) instead of images per GPU")
     ap.add_argument("--sharding", choices=["auto", "image", "instance"], default="instance",

@@ -400,9 +400,15 @@ def main():
         k = 8
         leg = run_leg(args.dtype, k, 1, 1, args.sharding)
         if rank == 0:
+            ms = int(S_STEPS * MIS)
+            p1, p2 = (N_INST + 1) * (ms + 1), S_STEPS - ms                   # forward pairs per image: shardable / per-image serial
             line["strong_scaling_leg"] = dict(global_images=k, value=round(leg["value"], 4), unit="img/s", steps=1, warmup=1,
                                               ms_per_step=round(leg["ms_per_step"], 2), sharding=args.sharding,
-                                              forward_rows_per_image=round((leg["rows_on"] + leg["rows_off"]) / k, 1))
+                                              forward_rows_per_image=round((leg["rows_on"] + leg["rows_off"]) / k, 1),
+                                              # phase 1 spreads over all ranks, phase 2 runs one trajectory per image: with fewer
+                                              # images than ranks only `k` ranks work in phase 2 (and on 2-row forwards)
+                                              amdahl_cap_vs_1gpu=round((p1 + p2) / (p1 / world + p2 / min(world, k)), 2),
+                                              ranks_idle_in_phase2=max(0, world - k))
     if world == 1 and not args.no_ref_batch_leg and not args.images_total and args.images_per_gpu != 8:
         # the reference's own batch: num_images = 8 per prompt (inference.py) on one GPU -- phase 1 runs
         # 72 units as 2 x 64-row + 1 x 16-row forwards per step, phase 2 16-row forwards

@@ -159,7 +159,7 @@ class PLMSSamplerInst(_PLMSBase):
     """Multi-instance Sampler, plms_instance.py:7-212."""
 
     def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None, mis=0.0,
-                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 32,
+                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 64,
                  unit_sharding: str = "auto"):
         super().__init__(diffusion, model, schedule, alpha_generator_func, set_alpha_scale)
         self.mis = mis

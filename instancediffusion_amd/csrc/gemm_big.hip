@@ -110,7 +110,7 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
         swap16(acc[a][b], v);
         const int m = mw + b * 32 + l31;
         if (m >= p.M) continue;
-        float* o = p.ws + ((size_t)slice * p.M + m) * p.N + n;
+        float* o = p.ws + ((size_t)slice * p.tail_rows + (m - p.tail_m0)) * p.N + n;
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + 4 * j) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
       }
@@ -348,18 +348,27 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   const int tiles_n = p.N / BN;
   // split-K (p.splitk > 1): work item seq = tile * splitk + slice covers K-tiles [slice * nk, (slice + 1) * nk) of its tile
   // and leaves fp32 partials in p.ws[slice][M][N] (reduced + epilogue by splitk_reduce_kernel)
+  // Hybrid (round 3): a tile count that is not close to a whole number of 256-CU rounds used to send the launch to the 128^2
+  // kernels (e.g. 288 tiles at 18 rows: 1.125 rounds); now the first `full` items are whole tiles and only the REMAINING
+  // tiles are cut into K-slices, one slice per otherwise idle workgroup (uniform split-K is the case full = 0).
   const int S = SPLIT ? p.splitk : 1;
-  const int nk = p.kt_per_slice;                            // K-tiles per work item (= K / BKT without split-K)
+  const int nk = p.kt_per_slice;                            // K-tiles per split item (= K / BKT without split-K)
+  const int full = SPLIT ? p.full_items : tiles_total;      // leading whole-tile items
+  auto item_map = [&](int item, int& tile, int& slice, int& nki) {
+    if (!SPLIT || item < full) { tile = item; slice = 0; nki = SPLIT ? p.kt_full : nk; }
+    else { const int r = item - full; const int t = r / S; tile = full + t; slice = r - t * S; nki = nk; }
+  };
 
   // ---------------- loader state (runs one K-tile ahead of the MFMAs, across output-tile boundaries)
   const int dr = lane / CPR, dc = lane % CPR;
   auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };   // conflict-free ds_read_b128 (see header)
   unsigned woff[W_INST], aoff[A_INST];
   int ayx[A_INST];                                        // conv: (yo*stride-1) << 16 | (xo*stride-1) & 0xffff
-  int l_seq, l_kt = 0, l_k0 = 0, tap = 0, ci0 = 0;
+  int l_seq, l_kt = 0, l_k0 = 0, l_nk = 0, tap = 0, ci0 = 0;
 
   auto setup_loader = [&](int item) {
-    const int tile = item / S, slice = item - tile * S;
+    int tile, slice;
+    item_map(item, tile, slice, l_nk);
     const int m_tile = tile / tiles_n;
     const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
     l_k0 = slice * nk;
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   };
   auto advance_loader = [&]() {
     if (CONV) { ci0 += BKT; if (ci0 >= p.Cin) { ci0 = 0; ++tap; } }
-    if (++l_kt == nk) {
+    if (++l_kt == l_nk) {
       l_kt = 0;
       l_seq += G;
       if (l_seq < tiles_total) setup_loader(l_seq);
@@ -496,8 +505,11 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   // One output tile: accumulators cleared, the K loop, the epilogue.  SWAPT = the transposed-V tiles of the fused q | k | v
   // projection.  The accumulators are LOCAL to a tile kind: with one accumulator block shared by the plain and the swapped
   // K loop the register allocator kept both MFMA forms' tied operands alive and spilled ~400 VGPRs (80 TF instead of 700).
-  auto run_tile = [&](auto SWAPT) {
+  auto run_tile = [&](auto SWAPT, auto SPLT) {
     constexpr bool SWAP = decltype(SWAPT)::value;
+    constexpr bool SPL = decltype(SPLT)::value;               // this item is one K-slice of a tail tile
+    int tile, slice, nki;
+    item_map(seq, tile, slice, nki);
     f32x16 acc[TN][TM];
     float lsx[TM], lsq[TM];                               // LNS: per-lane partial sum / sum of squares of its A rows
 #pragma unroll
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
 #pragma unroll
     for (int b = 0; b < TM; ++b) { lsx[b] = 0.0f; lsq[b] = 0.0f; }
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nki; ++kt) {
       // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt
       // wait followed by a barrier.  In steady state the NSTG-2 younger K-tiles stay in flight across the barrier
       // (counted wait; VM ops retire in order); at the tail of the stream fewer are outstanding -> wait for all.
@@ -564,17 +576,20 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, p.ln_stats, 0);
       }
     } else {
-      big_epilogue<DT, BM, BN, TN, SPLIT, LNS, STATS>(p, acc, seq / S, seq - (seq / S) * S, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
+      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
     }
   };
 
   for (; seq < tiles_total; seq += G) {
     if constexpr (VT) {
       // fused q | k | v projection: this tile's columns belong to V -> swapped operands, transposed store (workgroup-uniform)
-      if ((seq % tiles_n) * BN >= p.vt_col0) run_tile(IC<1>{});
-      else run_tile(IC<0>{});
+      if ((seq % tiles_n) * BN >= p.vt_col0) run_tile(IC<1>{}, IC<0>{});
+      else run_tile(IC<0>{}, IC<0>{});
+    } else if constexpr (SPLIT) {
+      if (seq < full) run_tile(IC<0>{}, IC<0>{});
+      else run_tile(IC<0>{}, IC<1>{});
     } else {
-      run_tile(IC<0>{});
+      run_tile(IC<0>{}, IC<0>{});
     }
   }
 }
@@ -608,8 +623,11 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
     attr_set = true;
   }
   CoreParams q = p;
-  q.splitk = splitk; q.kt_per_slice = p.K / BKT / splitk;
-  const int tiles = (p.N / BN) * ((p.M + BM - 1) / BM) * splitk;   // work items
+  q.splitk = splitk; q.kt_per_slice = p.K / BKT / splitk; q.kt_full = p.K / BKT;
+  const int tiles_all = (p.N / BN) * ((p.M + BM - 1) / BM);
+  if (!SPLIT) { q.full_items = tiles_all; q.tail_m0 = 0; q.tail_rows = p.M; }
+  // (SPLIT: full_items / tail_m0 / tail_rows were set by the dispatcher; uniform split-K = 0 / 0 / M)
+  const int tiles = q.full_items + (tiles_all - q.full_items) * splitk;   // work items
   const int slots = num_cu();
   const int grid = tiles < slots ? tiles : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BM * 2), smem, s, q, tiles);
@@ -621,9 +639,11 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
 std::atomic<long long> idf_stat_big_launches{0};
 
 // Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
-int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out, int* parts_out) {
+int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out, int* parts_out,
+                   int* tail_m0_out) {
   if (splitk_out) *splitk_out = 1;
   if (parts_out) *parts_out = 0;
+  if (tail_m0_out) *tail_m0_out = 0;
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
   if (p.K < 2 * BK || (p.K % BK) != 0) return IDF_BIG_UNSUPPORTED;
   if (p.epi & IDF_EPI_OUT_NCHW) return IDF_BIG_UNSUPPORTED;
@@ -663,14 +683,37 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
       break;
     }
   }
+  // full_items > 0: hybrid -- whole tiles for the leading full rounds, K-slices for the tail rows [tail_m0, M)
+  long long full_items = 0;
+  int tail_m0 = 0;
   if (!force) {
     // tile quantisation: a persistent workgroup slot processes ceil(items / slots) work items
     const long long items = tiles * splitk;
     const long long rounds = (items + slots - 1) / slots;
     const double eff = (double)items / (double)(rounds * slots);
-    if (eff < 0.80) return IDF_BIG_UNSUPPORTED;
+    if (eff < 0.80) {
+      // Hybrid (round 3): at least one full round of whole tiles, and the tiles beyond the last full round (whole m-tiles
+      // only, so that the tail is a row range) cut into S | K-tiles slices, one per workgroup of the last round.
+      const int tiles_n = p.N / bn;
+      const long long whole = ((tiles / slots) * slots / tiles_n) * tiles_n;
+      const long long rem = tiles - whole;
+      const int nkt = p.K / BK;
+      int S = 0;
+      if (splitk == 1 && splitk_out && tail_m0_out && whole > 0 && rem > 0 && bn != 128 && !geglu && !self_ln && !vt && p.ws)
+        for (int cand = (int)(slots / rem); cand >= 2; --cand) {
+          if (nkt % cand) continue;
+          S = cand;
+          break;
+        }
+      tail_m0 = (int)(whole / tiles_n) * bm;
+      if (S < 2 || (size_t)S * (size_t)(p.M - tail_m0) * p.N * sizeof(float) > p.ws_bytes) return IDF_BIG_UNSUPPORTED;
+      // worth it only if the tail round is short: its slices run nkt / S K-tiles plus a reducer pass over the tail rows
+      full_items = whole;
+      splitk = S;
+    }
   }
   if (splitk_out) *splitk_out = splitk;
+  if (tail_m0_out) *tail_m0_out = tail_m0;
   {                                                       // the loader uses 32-bit element offsets
     const unsigned long long rows = conv ? (unsigned long long)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win : (unsigned long long)p.M;
     if (rows * (unsigned long long)p.lda >= (1ull << 31) || (unsigned long long)p.N * p.ldw >= (1ull << 31)) return IDF_BIG_UNSUPPORTED;
@@ -681,6 +724,8 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
                      !(p.epi & IDF_EPI_OUT_F32) && (((uintptr_t)p.stat_parts) & 7u) == 0;
   CoreParams ps = p;
   if (stats) { ps.parts = 2 * (p.N / bn); *parts_out = ps.parts; }
+  CoreParams pq = p;                                      // split launches: uniform split-K (full 0) or hybrid
+  pq.full_items = (int)full_items; pq.tail_m0 = tail_m0; pq.tail_rows = p.M - tail_m0;
 #define IDF_BIG_DISPATCH(DT)                                                                                              \
   if (stats) return bn == 320 ? launch_big_cfg<DT, 320, 2, false, false, false, false, true>(ps, s)                        \
                               : launch_big_cfg<DT, 256, 2, false, false, false, false, true>(ps, s);                       \
@@ -689,8 +734,8 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
     if (conv) return launch_big_cfg<DT, 128, 3, true>(p, s);                                                              \
     return launch_big_cfg<DT, 128, 3, false>(p, s);                                                                       \
   }                                                                                                                       \
-  if (conv) return bn == 320 ? launch_big_cfg<DT, 320, 2, true>(p, s, splitk) : launch_big_cfg<DT, 256, 2, true>(p, s, splitk);     \
-  return bn == 320 ? launch_big_cfg<DT, 320, 2, false>(p, s, splitk) : launch_big_cfg<DT, 256, 2, false>(p, s, splitk);
+  if (conv) return bn == 320 ? launch_big_cfg<DT, 320, 2, true>(pq, s, splitk) : launch_big_cfg<DT, 256, 2, true>(pq, s, splitk);   \
+  return bn == 320 ? launch_big_cfg<DT, 320, 2, false>(pq, s, splitk) : launch_big_cfg<DT, 256, 2, false>(pq, s, splitk);
   if (dtype == IDF_BF16) { IDF_BIG_DISPATCH(IDF_BF16) }
   if (dtype == IDF_F16) { IDF_BIG_DISPATCH(IDF_F16) }
 #undef IDF_BIG_DISPATCH

@@ -494,12 +494,13 @@ template <int DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) {
   const int n8 = (p.N + 7) / 8;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)p.M * n8) return;
-  const int m = (int)(i / n8), n = (int)(i - (size_t)m * n8) * 8;
+  if (i >= (size_t)p.tail_rows * n8) return;                // the slabs cover rows [tail_m0, tail_m0 + tail_rows)
+  const int ml = (int)(i / n8), n = (int)(i - (size_t)ml * n8) * 8;
+  const int m = p.tail_m0 + ml;
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool vec = (n + 7 < p.N) && ((p.N & 3) == 0);
   for (int s = 0; s < p.splitk; ++s) {
-    const float* w = p.ws + ((size_t)s * p.M + m) * p.N + n;
+    const float* w = p.ws + ((size_t)s * p.tail_rows + ml) * p.N + n;
     if (vec) {
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4);
 #pragma unroll
@@ -552,6 +553,7 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   const int nk = p.K / BK;
   q.splitk = 1; q.kt_per_slice = nk;
+  q.tail_m0 = 0; q.tail_rows = p.M;                         // uniform split-K: the partial slabs cover every row
   // split-K when the tile grid cannot fill the 256 CUs (small-spatial / small-batch layers with long K)
   if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles < 192 && nk >= 8) {
     int want = (512 + tiles - 1) / tiles;
@@ -586,13 +588,13 @@ int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullp
   // quantisation heuristic), 2 forced whenever the shape qualifies.
   const int big = gemm_big_mode();
   if (big > 0 && batch == 1) {
-    int splitk = 1;
-    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out);
+    int splitk = 1, tail_m0 = 0;
+    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out, &tail_m0);
     if (rc != IDF_BIG_UNSUPPORTED) {
       if (rc == 0 && splitk > 1) {
         CoreParams q = p;
-        q.splitk = splitk;
-        const size_t n8 = (size_t)q.M * ((q.N + 7) / 8);
+        q.splitk = splitk; q.tail_m0 = tail_m0; q.tail_rows = p.M - tail_m0;
+        const size_t n8 = (size_t)q.tail_rows * ((q.N + 7) / 8);
         hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, q);
         return idf_launch_status();
       }

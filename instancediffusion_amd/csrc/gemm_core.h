@@ -14,7 +14,11 @@ struct CoreParams {
   const float* bias; const unsigned short* rowbias; int ld_rowbias; int rows_per_batch;
   const unsigned short* res; int ldr; long long strideR;
   const float* gate; int epi; int n_valid;
-  float* ws; size_t ws_bytes; int splitk; int kt_per_slice;   // split-K: fp32 partial slabs ws[slice][M][N]
+  float* ws; size_t ws_bytes; int splitk; int kt_per_slice;   // split-K: fp32 partial slabs ws[slice][tail_rows][N]
+  // hybrid split (persistent kernel): work items [0, full_items) are whole tiles (kt_full K-tiles, normal epilogue); the
+  // remaining tiles -- rows [tail_m0, tail_m0 + tail_rows) -- are cut into `splitk` K-slices each.  Uniform split-K:
+  // full_items = 0, tail_m0 = 0, tail_rows = M.
+  int full_items; int kt_full; int tail_m0; int tail_rows;
   // LayerNorm folded into the GEMM (IDF_EPI_LN_ROW / IDF_EPI_LN_COL, include/idf.h): (mu, rstd) pairs of the normalised
   // operand's rows, the column sums c of the gamma-folded weight and (LN_COL) the beta term d
   const float* ln_stats; long long stride_ln_stats; const float* ln_c; const float* ln_d;
@@ -128,6 +132,6 @@ extern std::atomic<long long> idf_stat_big_launches;     // process-global launc
 // *parts_out (optional): > 0 when the kernel left per-wave partial output-row statistics in p.stat_parts (p.stat_parts
 // offered and the launch was an unsplit dense GEMM), the number of slots per row.
 int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out,
-                   int* parts_out = nullptr);
+                   int* parts_out = nullptr, int* tail_m0_out = nullptr);
 // (mu, rstd) per row from `parts` equal-count (mean, M2) slots per row (fixed merge order): out_stats[m] = f32x2
 int idf_stats_finalize(const float* stat_parts, int parts, int cols_per_part, float* out_stats, int M, float eps, hipStream_t s);

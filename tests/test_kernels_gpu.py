@@ -570,6 +570,60 @@ def test_big_kernel_split_k(ops, ref):
     assert torch.equal(o1, o2)
 
 
+def test_big_kernel_hybrid_tail_split(ops, ref):
+    """Tile counts just above a whole number of 256-CU rounds (the 18-row forwards of a sharded / small batch: 288 tiles =
+    1.125 rounds) used to fall back to the 128^2 kernels.  Now the leading full rounds run whole tiles and the tail rows are
+    cut into K-slices (fp32 partials + reducer over the tail rows only).  Dense GEMM with every epilogue term, a 3x3 conv, and
+    bit-for-bit equality with the small-tile kernel on exact data; the launch counter shows the persistent kernel took them."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import pack_conv3x3
+    lib = _lib.load()
+    assert lib.idf_set_tuning(0, 1) in (0, 1, 2)                         # automatic dispatch
+    start = lib.idf_get_stat(0)
+    # 18 rows of the 64^2 level: M = 73728 -> 288 tiles of 256 x 320
+    M, N, K = 18 * 4096, 320, 320
+    a, w, bias = to16(gen((M, K), 165)), to16(gen((N, K), 166, K ** -0.5)), gen((N,), 167)
+    buf = dev(to16(gen((M, N), 168)))
+    want = buf.float().cpu() + a.float() @ w.float().t() + bias
+    ops.gemm(dev(a), dev(w), buf, bias=dev(bias), res=buf)
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 1, "288 tiles: persistent kernel with a split tail"
+    assert relmax(buf, want) < BF16_TOL and rel_rms(buf, want) < BF16_RMS_TOL
+    # ff-out shape (K = 1280: 20 K-tiles) with a partial last m-tile, exact data: equal to the small-tile kernel bit for bit
+    M2, N2, K2 = 18 * 4096 - 100, 320, 1280
+    g = torch.Generator().manual_seed(169)
+    ai = torch.randint(-3, 4, (M2, K2), generator=g).to(torch.bfloat16)
+    wi = torch.randint(-3, 4, (N2, K2), generator=g).to(torch.bfloat16)
+    o1 = ops.gemm(dev(ai), dev(wi), ops.empty((M2, N2)))
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 2
+    lib.idf_set_tuning(0, 0)
+    o2 = ops.gemm(dev(ai), dev(wi), ops.empty((M2, N2)))
+    torch.cuda.synchronize()
+    lib.idf_set_tuning(0, 1)
+    assert torch.equal(o1, o2)
+    assert torch.equal(o1.float().cpu(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float())
+    # conv 320 -> 320 at 64^2, batch 18 (288 tiles, 45 K-tiles), bias + time-embedding row bias + residual
+    B, H, W, Cin, Cout = 18, 64, 64, 320, 320
+    x = to16(gen((B, H, W, Cin), 170))
+    wp = to16(pack_conv3x3(gen((Cout, Cin, 3, 3), 171, (9 * Cin) ** -0.5)))
+    b = gen((Cout,), 172)
+    rowb, res = to16(gen((B, Cout), 173)), to16(gen((B, H, W, Cout), 174))
+    want = ref.conv3x3(x.float(), wp.float(), torch.empty(B, H, W, Cout), bias=b, rowbias=rowb.float(), res=res.float())
+    out = ops.conv3x3(dev(x), dev(wp), ops.empty((B, H, W, Cout)), bias=dev(b), rowbias=dev(rowb), res=dev(res))
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 3
+    assert relmax(out, want) < BF16_TOL and rel_rms(out, want) < BF16_RMS_TOL
+    # two n-tiles per row block (N = 640: 576 tiles = 2.25 rounds -> the tail starts on an m-tile boundary; 10 K-tiles, 2 slices)
+    M3, N3, K3 = 18 * 4096, 640, 640
+    ai = torch.randint(-3, 4, (M3, K3), generator=g).to(torch.bfloat16)
+    wi = torch.randint(-3, 4, (N3, K3), generator=g).to(torch.bfloat16)
+    o3 = ops.gemm(dev(ai), dev(wi), ops.empty((M3, N3)))
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 4
+    assert torch.equal(o3.float().cpu(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float())
+
+
 # ---------------------------------------------------------------------------------------------------
 # the 64-queries-per-wave attention kernel (attention4.hip), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------

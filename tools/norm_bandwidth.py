@@ -23,7 +23,9 @@ for name, v in k.items():
     if s is None:
         continue
     avg_us = float(s["AverageNs"]) / 1e3
-    rows.append(dict(kernel=name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60],
+    short = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    short = short[:short.index("(")] if "(" in short else short
+    rows.append(dict(kernel=short[:60],
                      launches_per_forward=round(int(s["Calls"]) / n_fwd, 1), avg_us=round(avg_us, 1),
                      fetch_MB=round(v["fetch_bytes_corrected_x2_avg"] / 1e6, 1), write_MB=round(v["write_bytes_avg"] / 1e6, 1),
                      hbm_MB_per_launch=round(v["hbm_bytes_per_launch"] / 1e6, 1),

@@ -7,10 +7,12 @@ into one per-kernel table: average counter value per dispatch, plus derived rati
 Normalised matrix-pipe numbers (the old `mfma_busy_over_sq_busy` was a ratio of two unnormalised sums):
   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)   -- SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed
       over the chip's SIMDs (32 per 32x32x16 bf16 MFMA, MI355X_MICROARCH.md); kernel cycles = GRBM_GUI_ACTIVE of the dispatch
+      (summed over the 8 XCDs by rocprofv3, hence / 8; `implied_clock_GHz` = cycles / duration is printed as a sanity check)
       when that counter was collected in a pass, else duration_ns x 2.1 GHz (flagged in `cycles_source`);
   useful_frac = mfma_busy_frac x --useful (the share of the issued MFMA work that is algorithmic: d = 40 attention pads
-      Q.K^T 40 -> 48 and P.V 40 -> 64, 640 useful of 896 issued cycles = 0.714) -- comparable with the timing-derived
-      fraction of the 2.5 PFLOP/s peak.
+      Q.K^T 40 -> 48 and P.V 40 -> 64, 640 useful of 896 issued cycles = 0.714): the fraction of the matrix pipe's capacity AT
+      THE CLOCK THE KERNEL RAN AT that did algorithmic work; x implied_clock / 2.4 GHz gives the fraction of the 2.5 PFLOP/s
+      spec peak that the timing shows.
 """
 import csv
 import glob
@@ -58,7 +60,10 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
             n_simd = 1024                                    # 256 CUs x 4 SIMDs
             if avg.get("GRBM_GUI_ACTIVE"):
-                cycles, row["cycles_source"] = avg["GRBM_GUI_ACTIVE"], "GRBM_GUI_ACTIVE"
+                # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (taken as one chip-wide count it would imply a
+                # 13.6 GHz clock on a 1.93 ms kernel); per-XCD average = chip cycles of the dispatch
+                cycles, row["cycles_source"] = avg["GRBM_GUI_ACTIVE"] / 8.0, "GRBM_GUI_ACTIVE / 8 XCDs"
+                row["implied_clock_GHz"] = round(cycles / max(row["avg_ns_under_profiler"], 1), 3)
             else:
                 cycles, row["cycles_source"] = row["avg_ns_under_profiler"] * 2.1, "duration_ns x 2.1 GHz (assumed clock)"
             row["mfma_busy_frac"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (n_simd * cycles), 4)

@@ -701,7 +701,10 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
       int S = 0;
       if (splitk == 1 && splitk_out && tail_m0_out && whole > 0 && rem > 0 && bn != 128 && !geglu && !self_ln && !vt && p.ws)
         for (int cand = (int)(slots / rem); cand >= 2; --cand) {
-          if (nkt % cand) continue;
+          // slices of >= 4 K-tiles: with shorter ones the slice prologues and the fp32 partial traffic cost more than the idle
+          // CUs they fill (K = 320, five one-K-tile slices: 200 -> 169 TF at 18 rows; K = 1280: 409 -> 500, 3x3 conv
+          // 536 -> 709 TF; profiles/r03_shape_profile_B18_hybrid.log)
+          if (nkt % cand || nkt / cand < 4) continue;
           S = cand;
           break;
         }

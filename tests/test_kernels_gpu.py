@@ -580,8 +580,8 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     lib = _lib.load()
     assert lib.idf_set_tuning(0, 1) in (0, 1, 2)                         # automatic dispatch
     start = lib.idf_get_stat(0)
-    # 18 rows of the 64^2 level: M = 73728 -> 288 tiles of 256 x 320
-    M, N, K = 18 * 4096, 320, 320
+    # 18 rows of the 64^2 level: M = 73728 -> 288 tiles of 256 x 320; K = 1280 (20 K-tiles -> 5 slices of 4)
+    M, N, K = 18 * 4096, 320, 1280
     a, w, bias = to16(gen((M, K), 165)), to16(gen((N, K), 166, K ** -0.5)), gen((N,), 167)
     buf = dev(to16(gen((M, N), 168)))
     want = buf.float().cpu() + a.float() @ w.float().t() + bias
@@ -622,6 +622,13 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     torch.cuda.synchronize()
     assert lib.idf_get_stat(0) - start == 4
     assert torch.equal(o3.float().cpu(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float())
+    # K = 320 (5 K-tiles): no slice count leaves >= 4 K-tiles per slice -> the launch goes to the small-tile kernels
+    ai = torch.randint(-3, 4, (18 * 4096, 320), generator=g).to(torch.bfloat16)
+    wi = torch.randint(-3, 4, (320, 320), generator=g).to(torch.bfloat16)
+    o4 = ops.gemm(dev(ai), dev(wi), ops.empty((18 * 4096, 320)))
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 4
+    assert torch.equal(o4.float().cpu(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float())
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -130,7 +130,7 @@ class OpTimer:
         def nb(t):
             return 0 if t is None else t.numel() * t.element_size()
         if name == "gemm":
-            return nb(a[0]) + nb(a[1]) + nb(a[2]) + nb(k.get("res")) + nb(k.get("bias"))
+            return nb(a[0]) + nb(a[1]) + nb(a[2]) + nb(k.get("res")) + nb(k.get("bias")) + nb(k.get("vt_out")) + nb(k.get("out_stats"))
         if name == "conv3x3":
             return nb(a[0]) + nb(a[1]) + nb(a[2]) + nb(k.get("res")) + nb(k.get("bias"))
         if name == "attention":

@@ -69,6 +69,24 @@ def test_argument_validation_without_gpu():
     assert lib.idf_gemm(ctypes.byref(ln_args(K=1600, lda=1600, ldw=1600)), None) == -1
     assert lib.idf_gemm(ctypes.byref(ln_args(ln_stats_out=0x60004)), None) == -2
     assert lib.idf_gemm(ctypes.byref(ln_args(epi=_lib.EPI_LN_ROW)), None) == -1          # the beta term travels as bias
+    # fused q | k | v projection (ABI 3: vt_out / ld_vt / vt_col0): argument errors are reported before any launch
+    def vt_args(**kw):
+        g = ln_args(N=960, vt_out=0x70000, ld_vt=256, vt_col0=640, ldo=640, ln_stats_out=0x60000)
+        for k, v in kw.items():
+            setattr(g, k, v)
+        return g
+    assert lib.idf_gemm(ctypes.byref(vt_args(vt_col0=0)), None) == -1                     # nothing left for `out`
+    assert lib.idf_gemm(ctypes.byref(vt_args(vt_col0=960)), None) == -1                   # nothing to transpose
+    assert lib.idf_gemm(ctypes.byref(vt_args(ld_vt=128)), None) == -1                     # rows of V^T shorter than M
+    assert lib.idf_gemm(ctypes.byref(vt_args(ld_vt=260)), None) == -1                     # 16-B row alignment
+    assert lib.idf_gemm(ctypes.byref(vt_args(batch=2, strideA=81920, strideO=163840)), None) == -1
+    assert lib.idf_gemm(ctypes.byref(vt_args(epi=_lib.EPI_BIAS | _lib.EPI_LN_ROW | _lib.EPI_SILU)), None) == -1
+    assert lib.idf_gemm(ctypes.byref(vt_args(out_stats=0x80000)), None) == -1
+    assert lib.idf_gemm(ctypes.byref(vt_args(ln_stats_out=None)), None) == -1             # self-normalising fallback needs them
+    # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
+    assert lib.idf_set_tuning(2, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 3) == -1
+    prev = lib.idf_set_tuning(1, 2)
+    assert prev in (0, 1, 2, 3) and lib.idf_set_tuning(1, prev) == 2
 
 
 def test_schema_matches_reference():

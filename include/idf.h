@@ -54,7 +54,11 @@ const char* idf_build_info(void);
 /* Kernel-selection knobs (process-global, for A/B measurement and for tests that must hit one specific kernel;
  * results are identical up to fp32 summation order).  Returns the previous value, or IDF_E_ARG for an unknown knob / value.
  *   IDF_TUNE_GEMM_BIG: 0 = never use the persistent 256 x {320,256,128}-tile GEMM/conv kernel, 1 = automatic
- *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies.  Initial value: env IDF_GEMM_BIG or the default (1).
+ *   (shape + tile-quantisation rule), 2 = whenever the shape qualifies, 3 = automatic + HYBRID TAIL SPLIT: a tile count just
+ *   above a whole number of 256-CU rounds (the 18-row forwards of a sharded / small batch) runs its leading full rounds as whole
+ *   tiles and cuts only the tail rows into K-slices instead of falling back to the 128x128 kernels (3x3 conv 536 -> 709 TF at
+ *   18 rows).  Opt-in, because the tail rows are then summed in another order than the rows of the whole tiles: identical
+ *   rows of one launch are no longer bitwise equal, the property modes 0..2 keep.  Initial value: env IDF_GEMM_BIG or the default (1).
  *   IDF_TUNE_ATTN2: 0 = attention always on the 32-queries-per-wave kernel; 1 = when the shape qualifies
  *   (d in {24,40,56}, n0 % 8 == n1 % 8 == 0, no mask) the 64-queries-per-wave LDS-DMA kernel (attention4.hip: max-free
  *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid) as two

@@ -589,7 +589,8 @@ int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullp
   const int big = gemm_big_mode();
   if (big > 0 && batch == 1) {
     int splitk = 1, tail_m0 = 0;
-    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out, &tail_m0);
+    // mode 3 = automatic + hybrid tail split (the dispatcher only cuts a tail when it is given somewhere to report it)
+    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out, big == 3 ? &tail_m0 : nullptr);
     if (rc != IDF_BIG_UNSUPPORTED) {
       if (rc == 0 && splitk > 1) {
         CoreParams q = p;
@@ -646,7 +647,7 @@ int idf_stats_finalize(const float* stat_parts, int parts, int cols_per_part, fl
 
 extern "C" int idf_set_tuning(int knob, int value) {
   if (knob == IDF_TUNE_GEMM_BIG) {
-    if (value < 0 || value > 2) return IDF_E_ARG;
+    if (value < 0 || value > 3) return IDF_E_ARG;
     const int prev = gemm_big_mode();
     g_big_mode = value;
     return prev;

@@ -84,7 +84,7 @@ def test_argument_validation_without_gpu():
     assert lib.idf_gemm(ctypes.byref(vt_args(out_stats=0x80000)), None) == -1
     assert lib.idf_gemm(ctypes.byref(vt_args(ln_stats_out=None)), None) == -1             # self-normalising fallback needs them
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
-    assert lib.idf_set_tuning(2, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 3) == -1
+    assert lib.idf_set_tuning(2, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
     prev = lib.idf_set_tuning(1, 2)
     assert prev in (0, 1, 2, 3) and lib.idf_set_tuning(1, prev) == 2
 

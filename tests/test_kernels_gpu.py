@@ -578,7 +578,7 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     from instancediffusion_amd import _lib
     from instancediffusion_amd.engine import pack_conv3x3
     lib = _lib.load()
-    assert lib.idf_set_tuning(0, 1) in (0, 1, 2)                         # automatic dispatch
+    prev_mode = lib.idf_set_tuning(0, 3)                                 # automatic dispatch + hybrid tail split (opt-in)
     start = lib.idf_get_stat(0)
     # 18 rows of the 64^2 level: M = 73728 -> 288 tiles of 256 x 320; K = 1280 (20 K-tiles -> 5 slices of 4)
     M, N, K = 18 * 4096, 320, 1280
@@ -600,7 +600,7 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     lib.idf_set_tuning(0, 0)
     o2 = ops.gemm(dev(ai), dev(wi), ops.empty((M2, N2)))
     torch.cuda.synchronize()
-    lib.idf_set_tuning(0, 1)
+    lib.idf_set_tuning(0, 3)
     assert torch.equal(o1, o2)
     assert torch.equal(o1.float().cpu(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float())
     # conv 320 -> 320 at 64^2, batch 18 (288 tiles, 45 K-tiles), bias + time-embedding row bias + residual
@@ -629,6 +629,13 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     torch.cuda.synchronize()
     assert lib.idf_get_stat(0) - start == 4
     assert torch.equal(o4.float().cpu(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float())
+    # default mode (1): no tail split -- 288 tiles go to the small-tile kernels, identical rows stay bitwise equal
+    lib.idf_set_tuning(0, 1)
+    same = to16(gen((1, K), 175)).expand(M, K).contiguous()
+    o5 = ops.gemm(dev(same), dev(w), ops.empty((M, N)))
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(0) - start == 4 and bool((o5 == o5[:1]).all())
+    lib.idf_set_tuning(0, prev_mode)
 
 
 # ---------------------------------------------------------------------------------------------------

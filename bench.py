@@ -70,7 +70,9 @@ def make_inputs(cfg, n_images, device):
     gb1 = synth.make_grounding_batch(1, boxes, g)
     x = torch.randn(n_images, 4, LATENT, LATENT, generator=g)
     ctx = torch.randn(n_images, 77, 768, generator=g)
-    uc = torch.randn(n_images, 77, 768, generator=g)
+    # ONE negative-prompt context for the whole batch, as inference.py builds it (text_encoder.encode(batch * [negative_prompt])):
+    # a stride-0 broadcast, so the samplers build that conditioning once (per-rank setup independent of the world size)
+    uc = torch.randn(1, 77, 768, generator=g)
     inst_ctx = [torch.randn(n_images, 77, 768, generator=g) for _ in range(N_INST)]
     gi = GroundingNetInput()
 
@@ -85,7 +87,7 @@ def make_inputs(cfg, n_images, device):
         inputs.append(dict(x=x.to(device), timesteps=None, context=inst_ctx[i].to(device),
                            grounding_input=gi.prepare(dev(synth.instance_batch(gb1, i)))))
     gi.prepare(dev(gb1))
-    return inputs, uc.to(device), gi, dict(gb=gb1, x=x, ctx=ctx)
+    return inputs, uc.to(device).expand(n_images, 77, 768), gi, dict(gb=gb1, x=x, ctx=ctx)
 
 
 class OpTimer:

@@ -45,7 +45,11 @@ enum {
    * "weight" operand is the token matrix).  ln_c is indexed the other way (n for LN_ROW, m for LN_COL); d travels as
    * `bias` (LN_ROW, needs BIAS) / `rowvec` (LN_COL).  With GEGLU both accumulators of a pair are corrected before the GELU. */
   IDF_EPI_LN_ROW   = 512,
-  IDF_EPI_LN_COL   = 1024
+  IDF_EPI_LN_COL   = 1024,
+  /* modifier of IDF_EPI_GEGLU: the weight rows are interleaved [16 value | 16 gate] per 32 instead of [32 | 32] per 64.  Value
+   * and gate of an output then sit in ONE 32-wide MFMA fragment (registers q and q + 2 of a lane), so the wave tile no longer
+   * needs an even number of fragments and the GEGLU GEMMs run on the 320-wide persistent tiles (N % 320 == 0). */
+  IDF_EPI_GEGLU_P32 = 2048
 };
 
 int idf_abi_version(void);

@@ -73,7 +73,9 @@ __device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigne
 // stores of each of its rows (BN/2 columns), accumulated around a per-lane pivot (no E[x^2] - mu^2 cancellation), the two
 // lane halves of a row merged with Chan's formula, one 8-B store per row and wave into p.stat_parts; a 16-B-per-row
 // finalize kernel replaces the pass that re-read the whole output (65 of them per forward in round 2).
-template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false, bool STATS = false>
+// GLU: the kernel instantiation that serves ONLY period-32 GEGLU launches on the 5-fragment (320-wide) wave tile: compiled with
+// nothing but that branch -- carrying it as a run-time branch in the other 320-wide kernels cost them ~290 spilled VGPRs.
+template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false, bool STATS = false, bool GLU = false>
 __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int slice, int tiles_n, int wm,
                                              int wn, int l31, int hi, float gate, const float* lnm = nullptr,
                                              const float* lnr = nullptr) {
@@ -117,8 +119,64 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
     });
     return;
   }
-  if (epi & IDF_EPI_GEGLU) {
-    if constexpr ((TN & 1) == 0) {
+  if (GLU || (((TN & 1) == 0) && (epi & IDF_EPI_GEGLU) && (epi & IDF_EPI_GEGLU_P32))) {
+   if constexpr (GLU || ((TN & 1) == 0)) {
+    // [16 value | 16 gate] per 32 packed rows: fragment a holds value (registers q = 0, 1) and gate (q = 2, 3) of 16 outputs
+    // in the same lane.  One v_permlane32_swap per register pair (q = 0 of the upper lanes <-> q = 1 of the lower lanes) leaves
+    // a lane with 8 consecutive output columns: one 16-B store.
+    static_for<0, TN, 1>([&](auto AI) {
+      constexpr int a = decltype(AI)::value;
+      const int npk = nw + a * 32;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        float o[8];
+        f32x2 st = {0.0f, 1.0f};
+        if (epi & IDF_EPI_LN_ROW) {
+          const int mr = min(mw + b * 32 + l31, p.M - 1);
+          if constexpr (LNS) st = f32x2{lnm[b], lnr[b]};
+          else st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)mr);
+        }
+        // bias / c vectors are (re)loaded per register group: keeping all of a fragment's 8 vectors live next to the 160
+        // accumulators spilled ~300 VGPRs (scratch is HBM traffic, see attention4.hip)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + npk + 8 * q + 4 * hi);
+          const f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + npk + 16 + 8 * q + 4 * hi);
+          f32x4 cv = {0.f, 0.f, 0.f, 0.f}, cg = {0.f, 0.f, 0.f, 0.f};
+          if (epi & IDF_EPI_LN_ROW) {
+            cv = *reinterpret_cast<const f32x4*>(p.ln_c + npk + 8 * q + 4 * hi);
+            cg = *reinterpret_cast<const f32x4*>(p.ln_c + npk + 16 + 8 * q + 4 * hi);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the same operation sequence as the period-64 branch below: the two packings give bit-identical outputs
+            float val = acc[a][b][4 * q + e], gat = acc[a][b][4 * (q + 2) + e];
+            if (epi & IDF_EPI_LN_ROW) {
+              val = fmaf(st[1], fmaf(-st[0], cv[e], val), bv[e]);
+              gat = fmaf(st[1], fmaf(-st[0], cg[e], gat), bg[e]);
+            } else {
+              val += bv[e];
+              gat += bg[e];
+            }
+            o[4 * q + e] = val * gelu_erf_f(gat);
+          }
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[e]), __float_as_uint(o[4 + e]), false, false);
+          v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+        }
+        const int m = mw + b * 32 + l31;
+        if (m < p.M) {
+          unsigned short* op = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + (npk >> 1) + 8 * hi;
+          *reinterpret_cast<u32x4*>(op) = pack8<DT>(v);
+        }
+      }
+    });
+   }
+  } else if (!GLU && (epi & IDF_EPI_GEGLU)) {
+    if constexpr (!GLU && (TN & 1) == 0) {
       static_for<0, TN, 2>([&](auto AI) {
         constexpr int a = decltype(AI)::value;
         const int npk = nw + a * 32;                    // packed weight rows: [32 value | 32 gate]
@@ -166,7 +224,7 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
         }
       });
     }
-  } else {
+  } else if constexpr (!GLU) {
     float st_p[TM], st_s1[TM], st_s2[TM];                  // STATS: pivot, sum (x - p), sum (x - p)^2 per row fragment
 #pragma unroll
     for (int b = 0; b < TM; ++b) { st_p[b] = 0.0f; st_s1[b] = 0.0f; st_s2[b] = 0.0f; }
@@ -324,7 +382,8 @@ __device__ __forceinline__ void big_epilogue_vt(const CoreParams& p, f32x16 (&ac
 
 // Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
 //   <256, {320,256}, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages); <256, 128, 64, 3>: 3 x 48 KB stages.
-template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false, bool STATS = false>
+template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false, bool STATS = false,
+          bool GLU = false>
 __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
   constexpr int WN = BN / 2, TN = WN / 32;
   constexpr int NW = BM / 32;                              // waves per workgroup (8 or 4)
@@ -576,7 +635,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, p.ln_stats, 0);
       }
     } else {
-      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
+      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
     }
   };
 
@@ -605,16 +664,16 @@ int num_cu() {
   return g_num_cu;
 }
 
-template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false, bool STATS = false>
+template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false, bool STATS = false, bool GLU = false>
 int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   constexpr int BM = 256, BKT = 64;
-  if constexpr (!SPLIT && !LNS && !VT && !STATS && NSTG == 2) {
+  if constexpr (!SPLIT && !LNS && !VT && !STATS && !GLU && NSTG == 2) {
     if (splitk > 1) return launch_big_cfg<DT, BN, NSTG, CONV, true>(p, s, splitk);
   }
   if constexpr (!SPLIT && !LNS && !CONV && !STATS && NSTG == 2) {
-    if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT>(p, s, 1);
+    if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT, false, GLU>(p, s, 1);
   }
-  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS>;
+  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS, GLU>;
   constexpr int smem = NSTG * (BM + BN) * BKT * 2 + ((VT && LNS) ? 8 * 128 * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
@@ -663,7 +722,8 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if (vt && (conv || geglu || (p.N % 320) || (p.vt_col0 % 320) || p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.M % 16) || (p.ld_vt % 8) ||
              !aligned16(p.vt_out) || (p.epi & ~(IDF_EPI_BIAS | IDF_EPI_LN_ROW)))) return IDF_BIG_UNSUPPORTED;
   int bn = 0;
-  if (geglu) bn = (p.N % 256 == 0) ? 256 : 0;
+  if (geglu && (p.epi & IDF_EPI_GEGLU_P32)) bn = (p.N % 320 == 0) ? 320 : ((p.N % 256 == 0) ? 256 : 0);
+  else if (geglu) bn = (p.N % 256 == 0) ? 256 : 0;
   else if (p.N % 320 == 0) bn = 320;
   else if (p.N % 256 == 0) bn = 256;
   else if (p.N % 128 == 0 && !self_ln) bn = 128;
@@ -729,7 +789,9 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   if (stats) { ps.parts = 2 * (p.N / bn); *parts_out = ps.parts; }
   CoreParams pq = p;                                      // split launches: uniform split-K (full 0) or hybrid
   pq.full_items = (int)full_items; pq.tail_m0 = tail_m0; pq.tail_rows = p.M - tail_m0;
+  const bool glu320 = geglu && (p.epi & IDF_EPI_GEGLU_P32) && bn == 320;
 #define IDF_BIG_DISPATCH(DT)                                                                                              \
+  if (glu320) return launch_big_cfg<DT, 320, 2, false, false, false, false, false, true>(p, s);                           \
   if (stats) return bn == 320 ? launch_big_cfg<DT, 320, 2, false, false, false, false, true>(ps, s)                        \
                               : launch_big_cfg<DT, 256, 2, false, false, false, false, true>(ps, s);                       \
   if (vt) return launch_big_cfg<DT, 320, 2, false, false, false, true>(p, s);                                             \

@@ -54,30 +54,32 @@ __device__ __forceinline__ void tile_epilogue(const CoreParams& p, f32x16 (&acc)
   const int mw = m0 + wm * WM, nw = n0 + wn * WN;
   if (epi & IDF_EPI_GEGLU) {
     if constexpr (WN >= 64) {
-      // wave columns are [32 value | 32 gate] per 64; a lane pairs value chunk c with gate chunk c of one row
+      // wave columns are [P/2 value | P/2 gate] per P (P = 64, or 32 with IDF_EPI_GEGLU_P32); a lane pairs value chunk c with
+      // the gate chunk of the same outputs of one row
       constexpr int CHV = WN / 16;                               // value chunks (8 columns each) per row
       constexpr int RPP = 64 / CHV;                              // rows per pass
+      const int P = (epi & IDF_EPI_GEGLU_P32) ? 32 : 64, half = P >> 1, cpg = P >> 4;   // value chunks per group
 #pragma unroll
       for (int pass = 0; pass < WM / RPP; ++pass) {
         const int row = pass * RPP + lane / CHV, c = lane % CHV;
-        const int pair = c >> 2, cc = c & 3;
+        const int grp = c / cpg, cc = c - grp * cpg;
         const int m = mw + row;
-        const int npk = nw + pair * 64 + cc * 8;                 // packed weight row of the value columns
-        if (m < p.M && npk + 32 < p.N) {
-          const float* src = Cl + row * CSTR + pair * 64 + cc * 8;
+        const int npk = nw + grp * P + cc * 8;                   // packed weight row of the value columns
+        if (m < p.M && npk + half < p.N) {
+          const float* src = Cl + row * CSTR + grp * P + cc * 8;
           float v[8], g[8];
           *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
           *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
-          *reinterpret_cast<f32x4*>(g) = *reinterpret_cast<const f32x4*>(src + 32);
-          *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(src + 36);
+          *reinterpret_cast<f32x4*>(g) = *reinterpret_cast<const f32x4*>(src + half);
+          *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(src + half + 4);
           const f32x4 bv0 = *reinterpret_cast<const f32x4*>(p.bias + npk), bv1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 4);
-          const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + npk + 32), bg1 = *reinterpret_cast<const f32x4*>(p.bias + npk + 36);
+          const f32x4 bg0 = *reinterpret_cast<const f32x4*>(p.bias + npk + half), bg1 = *reinterpret_cast<const f32x4*>(p.bias + npk + half + 4);
           if (epi & IDF_EPI_LN_ROW) {                            // LayerNorm folded in (gemm_core.h epilogue8 has the plain form)
             const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + (size_t)bz * p.stride_ln_stats + 2 * (size_t)m);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               v[e] = st[1] * fmaf(-st[0], p.ln_c[npk + e], v[e]);
-              g[e] = st[1] * fmaf(-st[0], p.ln_c[npk + 32 + e], g[e]);
+              g[e] = st[1] * fmaf(-st[0], p.ln_c[npk + half + e], g[e]);
             }
           }
 #pragma unroll
@@ -85,7 +87,7 @@ __device__ __forceinline__ void tile_epilogue(const CoreParams& p, f32x16 (&acc)
             v[e] = (v[e] + bv0[e]) * gelu_erf_f(g[e] + bg0[e]);
             v[e + 4] = (v[e + 4] + bv1[e]) * gelu_erf_f(g[e + 4] + bg1[e]);
           }
-          const int j = (nw + pair * 64) / 2 + cc * 8;
+          const int j = (nw + grp * P) / 2 + cc * 8;
           unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)bz * p.strideO + (size_t)m * p.ldo + j;
           if ((p.ldo & 7) == 0) {
             *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
@@ -673,6 +675,7 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   if ((a->epi & IDF_EPI_RES) && !a->res) return IDF_E_ARG;
   if ((a->epi & (IDF_EPI_BIAS | IDF_EPI_GEGLU)) && !a->bias) return IDF_E_ARG;
   if ((a->epi & IDF_EPI_GEGLU) && ((a->N % 64) || (a->ldo % 4))) return IDF_E_ARG;
+  if ((a->epi & IDF_EPI_GEGLU_P32) && !(a->epi & IDF_EPI_GEGLU)) return IDF_E_ARG;
   if ((a->epi & IDF_EPI_ROWBIAS) && (!a->rowbias || a->rows_per_batch <= 0)) return IDF_E_ARG;
   if (a->epi & IDF_EPI_OUT_NCHW) return IDF_E_ARG;
   CoreParams p{};

@@ -36,14 +36,25 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def pack_geglu(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """attention.py:36-43: proj -> chunk(2) = (value, gate).  Interleave rows as [32 value | 32 gate] per 64 so that
-    one wave's two 32-wide MFMA column tiles hold value and gate of the SAME output columns (in-register GEGLU)."""
+# GEGLU weight-row interleave period (A/B switch, env IDF_GEGLU_PERIOD): 64 = [32 value | 32 gate] (value and gate of an output in
+# the two MFMA fragments of a pair: even fragment count per wave, 256-wide tiles), 32 = [16 value | 16 gate] (both in ONE
+# fragment: the GEGLU GEMMs run on the 320-wide persistent tiles -- 9 LDS-DMA instructions per 40 MFMAs instead of 8 per 32,
+# and 20 % fewer tiles re-reading the activation rows).
+GEGLU_PERIOD = int(os.environ.get("IDF_GEGLU_PERIOD", "32"))
+if GEGLU_PERIOD not in (32, 64):
+    raise ValueError(f"IDF_GEGLU_PERIOD={GEGLU_PERIOD}: must be 32 or 64")
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor, period: int = 64) -> Tuple[torch.Tensor, torch.Tensor]:
+    """attention.py:36-43: proj -> chunk(2) = (value, gate).  Interleave rows as [P/2 value | P/2 gate] per P so that value and
+    gate of the SAME output columns sit in one lane's accumulators (in-register GEGLU): P = 64 -> the two 32-wide MFMA column
+    tiles of a pair, P = 32 -> registers q and q + 2 of one tile."""
     n2, k = w.shape
     n = n2 // 2
-    assert n % 32 == 0
-    wv, wg = w[:n].reshape(n // 32, 32, k), w[n:].reshape(n // 32, 32, k)
-    bv, bg = b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)
+    h = period // 2
+    assert n % h == 0
+    wv, wg = w[:n].reshape(n // h, h, k), w[n:].reshape(n // h, h, k)
+    bv, bg = b[:n].reshape(n // h, h), b[n:].reshape(n // h, h)
     return torch.cat([wv, wg], dim=1).reshape(n2, k).contiguous(), torch.cat([bv, bg], dim=1).reshape(n2).contiguous()
 
 
@@ -168,10 +179,10 @@ class UNetEngine:
         return w16, w16.float().sum(1).contiguous(), self._f32(d)
 
     def _pack_ff(self, ff, norm):
-        """GEGLU feed-forward behind LayerNorm `norm`: proj rows interleaved [32 value | 32 gate] (pack_geglu), gamma folded."""
+        """GEGLU feed-forward behind LayerNorm `norm`: proj rows interleaved value | gate per GEGLU_PERIOD (pack_geglu), gamma folded."""
         w = ff.net[0].proj.weight.detach().float()
         g, b = norm.weight.detach().float(), norm.bias.detach().float()
-        wp, dp = pack_geglu(w * g[None, :], ff.net[0].proj.bias.detach().float() + w @ b)
+        wp, dp = pack_geglu(w * g[None, :], ff.net[0].proj.bias.detach().float() + w @ b, GEGLU_PERIOD)
         w16 = self._w16(wp)
         return dict(w1=w16, b1=self._f32(dp), c1=w16.float().sum(1).contiguous(), l2=self._lin(ff.net[2]))
 
@@ -571,7 +582,7 @@ class UNetEngine:
         produced y: a GEGLU GEMM has 8-16 column tiles per row block, each of which would repeat the in-loop row sums --
         measured +15 % on those launches -- so here the separate 8-B-per-row pass is the cheaper form)."""
         ops = self.ops
-        mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True,
+        mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True, geglu_period=GEGLU_PERIOD,
                        ln_row=(None if LN_SELF_MODE == 2 else st, f["c1"]))
         return ops.gemm(mid, f["l2"].w, y, bias=f["l2"].b, res=y, gate=gate, out_stats=out_stats)
 

@@ -12,8 +12,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GATE, EPI_GEGLU, EPI_GELU, EPI_LN_COL, EPI_LN_ROW, EPI_OUT_F32, EPI_OUT_NCHW, EPI_RES,
-                   EPI_ROWBIAS, EPI_SILU)
+from ._lib import (EPI_BIAS, EPI_GATE, EPI_GEGLU, EPI_GEGLU_P32, EPI_GELU, EPI_LN_COL, EPI_LN_ROW, EPI_OUT_F32, EPI_OUT_NCHW,
+                   EPI_RES, EPI_ROWBIAS, EPI_SILU)
 
 _DT = {torch.bfloat16: _lib.IDF_BF16, torch.float16: _lib.IDF_F16}
 
@@ -67,10 +67,11 @@ class HipOps:
 
     # ------------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None,
-             act: Optional[str] = None, geglu: bool = False, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5,
+             act: Optional[str] = None, geglu: bool = False, geglu_period: int = 64, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5,
              ln_eps=1e-5, ln_stats_out=None, vt_out=None):
         """out[..,M,N] = epi(a[..,M,K] @ w[..,N,K]^T).  2-D or batched 3-D views; a/w may be shared (2-D) in a
-        batched call.  geglu: ``w``/``bias`` are in the packed [32 value | 32 gate] row order, out has N/2 cols.
+        batched call.  geglu: ``w``/``bias`` are in the packed [P/2 value | P/2 gate] row order (``geglu_period`` P = 64 or 32,
+        engine.pack_geglu), out has N/2 cols.
         ln_row = (stats [.., M, 2], c [N]): ``a`` is the RAW input of a LayerNorm whose gamma is folded into ``w`` and whose
         beta term travels in ``bias`` (include/idf.h IDF_EPI_LN_ROW).  ln_col = (stats [.., N, 2], c [M], d [M]): the same
         with the normalised operand on the ``w`` side (transposed-V projection).  out_stats [.., M, 2]: also emit (mu, rstd)
@@ -102,6 +103,9 @@ class HipOps:
             raise ValueError(act)
         if geglu:
             epi |= EPI_GEGLU
+            assert geglu_period in (32, 64)
+            if geglu_period == 32:
+                epi |= EPI_GEGLU_P32
             assert out.shape[-1] == N // 2
         elif vt_out is not None:
             assert not batched and out.shape[-2] == M and vt_out.shape[0] == N - out.shape[-1] and vt_out.shape[1] >= M

@@ -42,7 +42,7 @@ class EmulOps:
 
     # ----------------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, bias=None, rowbias=None, rows_per_batch=0, res=None, gate=None, act=None, geglu=False,
-             ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5, ln_eps=1e-5, ln_stats_out=None, vt_out=None):
+             geglu_period=64, ln_row=None, ln_col=None, out_stats=None, out_stats_eps=1e-5, ln_eps=1e-5, ln_stats_out=None, vt_out=None):
         self._count("gemm")
         assert a.dtype == self.dtype and w.dtype == self.dtype
         assert a.shape[-1] % 64 == 0, "K % 64"
@@ -74,7 +74,8 @@ class EmulOps:
         if geglu:
             n2 = acc.shape[-1]
             acc = acc + bias
-            blocks = acc.reshape(*acc.shape[:-1], n2 // 64, 2, 32)
+            half = geglu_period // 2
+            blocks = acc.reshape(*acc.shape[:-1], n2 // geglu_period, 2, half)
             v = blocks[..., 0, :] * F.gelu(blocks[..., 1, :])
             out.copy_(v.reshape(*acc.shape[:-1], n2 // 2))
             return out

@@ -807,6 +807,44 @@ def test_gemm_layernorm_self_stats(ops, M, N, K, geglu):
     assert mu_err < 1e-4 and rs_rel < 1e-4
 
 
+@pytest.mark.parametrize("M,C,stats", [(65536, 320, "given"), (65536, 320, "self"), (16384, 640, "given"), (4096, 1280, "none"),
+                                       (200, 320, "given"), (1000, 320, "self")])
+def test_gemm_geglu_period32(ops, M, C, stats):
+    """IDF_EPI_GEGLU_P32: weight rows interleaved [16 value | 16 gate] per 32, value and gate of an output in ONE MFMA fragment,
+    so the GEGLU GEMMs (N = 8C: 2560 / 5120 / 10240, all multiples of 320) run on the 320-wide persistent tiles.  Against the
+    fp32 reference, and BIT FOR BIT against the period-64 packing of the same weights (same K order per output element, same
+    epilogue arithmetic); small M exercises the 128x128 kernels' form of the same epilogue."""
+    import torch.nn.functional as F
+    from instancediffusion_amd.engine import pack_geglu
+    K, N = C, 8 * C
+    gamma, beta = 1 + 0.2 * gen((K,), 181), 0.3 * gen((K,), 182)
+    x = to16(gen((M, K), 183) * 1.5 + 0.5 * gen((M, 1), 184))
+    w, b = gen((N, K), 185, K ** -0.5), 0.2 * gen((N,), 186)
+    outs = {}
+    for period in (32, 64):
+        if stats == "none":
+            wp, bp = pack_geglu(to16(w).float(), b, period)
+            outs[period] = ops.gemm(dev(x), dev(to16(wp)), ops.empty((M, N // 2)), bias=dev(bp), geglu=True, geglu_period=period)
+            want_h = x.float() @ to16(w).float().t() + b
+        else:
+            wp, dp = pack_geglu(w * gamma[None, :], b + w @ beta, period)
+            w16 = to16(wp)
+            st = ops.empty((M, 2), torch.float32)
+            if stats == "given":
+                ops.row_stats(dev(x), st, 1e-5)
+            outs[period] = ops.gemm(dev(x), dev(w16), ops.empty((M, N // 2)), bias=dev(dp), geglu=True, geglu_period=period,
+                                    ln_row=(st if stats == "given" else None, dev(w16.float().sum(1))),
+                                    ln_stats_out=st if stats == "self" else None)
+            want_h = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    torch.cuda.synchronize()
+    want = want_h[:, :N // 2] * F.gelu(want_h[:, N // 2:])
+    err, mx = rel_rms(outs[32], want), relmax(outs[32], want)
+    print(f"[parity] GEGLU period 32 M{M} C{C} stats={stats}: rel-rms {err:.3e} max-rel {mx:.3e}; equal to period 64: "
+          f"{torch.equal(outs[32], outs[64])}")
+    assert mx < BF16_TOL and err < BF16_TOL / 2
+    assert torch.equal(outs[32], outs[64])
+
+
 @pytest.mark.parametrize("ratio", [10.0, 100.0])
 def test_gemm_layernorm_self_stats_large_mean_bound(ops, ratio):
     """the in-loop row sums of the persistent kernel are single-pass (sum x, sum x^2 by v_dot2c, fp32), so a row

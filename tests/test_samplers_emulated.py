@@ -187,3 +187,31 @@ def test_mis_sharded_world3_more_ranks_than_images_gloo():
     print(f"[world 3, instance] attention rows: single process {single}, per rank {rows}")
     assert all(0 < n < single for n in rows), (single, rows)
     assert max(rows) <= 0.60 * single and sum(rows) <= 1.30 * single, (single, rows)
+
+
+def test_shared_unconditional_row_is_built_once_and_changes_nothing(monkeypatch):
+    """inference.py encodes ONE negative prompt for the whole batch: identical unconditional rows (a stride-0 broadcast, or equal
+    values) are prepared once and every image gathers the same bank row (with `instance` ownership the uncond set is
+    the whole global batch).  Same trajectory as with one prepared row per image, bit for bit, with fewer prepared rows."""
+    from instancediffusion_amd.host import samplers as smp
+    outs, prepared = [], []
+    for shared in (True, False):
+        gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
+        if not shared:
+            monkeypatch.setattr(smp, "guided_uc_shared", lambda uc: False)
+        eng = model.engine
+        rows = [0]
+        real = eng.prepare_cond
+
+        def counting(context, grounding, _real=real, _rows=rows):
+            _rows[0] += int(context.shape[0])
+            return _real(context, grounding)
+        eng.prepare_cond = counting
+        sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
+                                  set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+        uc1 = inp["uc"][:1].expand(inp["uc"].shape[0], 77, 768)
+        outs.append(sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=uc1,
+                                   guidance_scale=7.5))
+        prepared.append(rows[0])
+    assert torch.equal(outs[0], outs[1])
+    assert prepared[0] == prepared[1] - (inp["uc"].shape[0] - 1), prepared

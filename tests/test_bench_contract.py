@@ -23,10 +23,11 @@ def test_make_inputs_equals_materialised_construction():
     gb = synth.make_grounding_batch(n, boxes, g)
     x = torch.randn(n, 4, bench.LATENT, bench.LATENT, generator=g)
     ctx = torch.randn(n, 77, 768, generator=g)
-    uc2 = torch.randn(n, 77, 768, generator=g)
+    uc2 = torch.randn(1, 77, 768, generator=g)         # ONE negative-prompt context, broadcast (as inference.py encodes it)
     ic = [torch.randn(n, 77, 768, generator=g) for _ in range(bench.N_INST)]
     assert len(inputs) == bench.N_INST + 1
-    assert torch.equal(inputs[0]["x"], x) and torch.equal(inputs[0]["context"], ctx) and torch.equal(uc, uc2)
+    assert torch.equal(inputs[0]["x"], x) and torch.equal(inputs[0]["context"], ctx)
+    assert uc.shape == (n, 77, 768) and uc.stride(0) == 0 and torch.equal(uc[1], uc2[0])
     ref0 = gi.prepare(gb)
     assert all(torch.equal(v, ref0[k]) for k, v in inputs[0]["grounding_input"].items())
     for i in range(bench.N_INST):

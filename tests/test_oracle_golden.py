@@ -107,9 +107,12 @@ def test_full_size_c4_forward_matches_reference():
         _check(ref_cpu.unet_forward(sd, cfg, inp["x"], inp["t"], inp["context"], objs), gold["eps_cond"], FWD_TOL, "C4 eps_cond")
 
 
-@pytest.mark.slow
+@heavy
 def test_full_size_forward_matches_reference():
-    """Full SD-1.5 InstanceDiffusion UNet (1.228 B params), C1 inputs (demo_cat_dog_robin boxes), 64x64 latent."""
+    """Full SD-1.5 InstanceDiffusion UNet (1.228 B params), C1 inputs (demo_cat_dog_robin boxes), 64x64 latent.  Opt-in since
+    round 3: its 12 GB of fp32 weights + synthesis left the test process under memory reclaim in this VM, and every test after
+    it ran 10-50x slower (the whole CPU suite 8 min -> more than an hour); the full-size oracle is pinned on the GPU box by
+    smoke() and by the live-oracle tests, and the recorded opt-in runs are profiles/r03_oracle_full_s50.log (trajectory, 1.4e-6)."""
     gold, meta, cfg, sd, inp = _setup("full_box_c1")
     assert sum(v.numel() for v in sd.values()) == 1228333437
     with torch.no_grad():

@@ -380,6 +380,24 @@ __device__ __forceinline__ void big_epilogue_vt(const CoreParams& p, f32x16 (&ac
   });
 }
 
+// Optional per-segment cycle trace (tools/ubench/big_trace.hip builds this file with -DIDF_BIG_TRACE; the library build has
+// none of it): s_memtime deltas summed per segment by waves 0 (early filler) and 4 (late filler) of the first and of a
+// middle workgroup.  Segments: 0 vmcnt wait, 1 barrier, 2 early K-tile enqueue, 3 fragment reads + MFMA issue (+ late
+// enqueue), 4 epilogue, 5 tile head (accumulator clear), 6 number of K-tiles, 7 number of tiles.
+#ifdef IDF_BIG_TRACE
+__device__ unsigned long long idf_big_trace_buf[4][8];
+#define TR_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
+#define TR_COUNT(i) { tr_acc[i] += 1; }
+#define TR_DUMP { const int trb = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1);                     \
+    if (trb >= 0 && lane == 0 && (wave == 0 || wave == 4)) { for (int i = 0; i < 8; ++i) idf_big_trace_buf[trb * 2 + (wave >> 2)][i] = tr_acc[i]; } }
+#else
+#define TR_DECL
+#define TR(i)
+#define TR_COUNT(i)
+#define TR_DUMP
+#endif
+
 // Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
 //   <256, {320,256}, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages); <256, 128, 64, 3>: 3 x 48 KB stages.
 template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false, bool STATS = false,
@@ -497,6 +515,17 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   const int f_sw = swz(l31);                              // fragment rows are (multiple of 32) + l31
   int issued = 0;                                         // K-tiles enqueued so far
   constexpr int NPOS = (BKT / 16) * TN;                   // (k-step, weight fragment) positions of a K-tile: TM MFMAs each
+  // Fill schedule (see the K loop).  OLD_LATE: which half of the workgroup enqueues the next K-tile from inside its MFMAs --
+  // the OLDER waves 0..3 (320-wide tiles, at 7/8 of their MFMAs) or the younger waves 4..7 (at 1/2: the round-2 schedule,
+  // kept for the 256- and 128-wide tiles, where the new one measured no better).  -DIDF_LATE_OLD / _NUM / _DEN: the
+  // experiment knobs of tools/ubench/big_trace.hip.
+#ifdef IDF_LATE_NUM
+  constexpr bool OLD_LATE = IDF_LATE_OLD != 0;
+  constexpr int LATE_POS = NPOS * IDF_LATE_NUM / IDF_LATE_DEN;
+#else
+  constexpr bool OLD_LATE = BN == 320;
+  constexpr int LATE_POS = OLD_LATE ? NPOS * 7 / 8 : NPOS / 2;
+#endif
   // `late_fill`: this wave enqueues the next K-tile's LDS-DMA pieces from the MIDDLE of its MFMAs (see the K loop).
   // SWAPT: MFMA operands swapped (transposed-V tiles of the fused q | k | v projection): acc[a][b] then holds
   // D[m = b*32 + 8q + 4hi + e][n = a*32 + l31] -- a lane owns a channel, its registers run over tokens.
@@ -541,7 +570,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
               Elem<DT>::dot2c(lsq[b], af[cur][b][w], af[cur][b][w]);
             }
         }
-        if constexpr (pos == NPOS / 2 - 1) {
+        if constexpr (pos == LATE_POS - 1) {
           if (late_fill) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
         }
       });
@@ -558,6 +587,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   for (int j = 0; j < NSTG - 1; ++j)
     if (l_seq < tiles_total) { issue_dma(j); ++issued; }
   int it = 0, st_it = 0;                                  // K-tile consumed next and its ring stage
+  TR_DECL
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
 
@@ -579,6 +609,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 #pragma unroll
     for (int b = 0; b < TM; ++b) { lsx[b] = 0.0f; lsq[b] = 0.0f; }
+    TR(5) TR_COUNT(7)
 
     for (int kt = 0; kt < nki; ++kt) {
       // K-tile `it` must have landed: an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt
@@ -586,22 +617,33 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       // (counted wait; VM ops retire in order); at the tail of the stream fewer are outstanding -> wait for all.
       if (NSTG > 2 && issued - it == NSTG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * DPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TR(0)
       __builtin_amdgcn_s_barrier();                       // ... and every wave has finished reading the stage refilled below
       asm volatile("" ::: "memory");
-      // An LDS-DMA instruction holds the issuing wave for ~180-240 cycles (tools/ubench/dma_rate.hip: 5.6 B/clk per wave,
-      // 34 B/clk per CU), during which it issues no MFMA.  The fill is therefore SKEWED: waves 0-3 enqueue the next K-tile
-      // right behind the barrier, waves 4-7 -- the partner wave on every SIMD -- from the middle of their MFMAs, so one wave
-      // of a SIMD feeds the matrix pipe while the other is held in the memory pipe (measured against end-of-tile and spread
-      // schedules in round 2: profiles/r02_shape_profile_B64_fill_*.log).
+      TR(1)
+      // An LDS-DMA piece holds the issuing wave for 55-72 cycles (tools/ubench/dma_mix.hip: 14 B/clk per wave, 64 B/clk per
+      // CU -- round 2's 5.6 / 34 came out of a ubench whose address update was a 64-bit modulo), i.e. ~550 cycles per K-tile
+      // during which it issues no MFMA.  The fill is therefore SKEWED between the two waves of a SIMD: one enqueues the next
+      // K-tile right behind the barrier, its partner from inside its MFMAs.  Round 3 (late): MFMA issue arbitration is
+      // OLDEST WAVE FIRST (tools/ubench/mfma_sustain.hip: of two waves streaming MFMAs on one SIMD, wave 0 finishes ALL of
+      // its stream before wave 4 gets a slot), so with the round-2 roles the younger, late-filling wave was starved until
+      // the older one had finished its K-tile, and only then reached its own enqueue point -- ~550 cycles of its DMA issue with
+      // the matrix pipe idle (cycle trace: profiles/r03_big_trace_baseline.log).  Now the OLDER waves 0-3 are the late ones
+      // (at 7/8 of their MFMAs: their blocked time is the younger wave's turn) and the younger waves 4-7 enqueue first, under
+      // the older wave's MFMAs: K-tile period 3770 -> 3190 cycles at K = 5120; in time -2...-9 % per launch
+      // (profiles/r03_big_sched_ab.log), less than in cycles because the chip is power-limited here: the shader clock falls as
+      // the pipe fills (clock x pipe-busy ~ constant ~ 1.0-1.2 GHz across all schedules, r03_big_trace_variants*.log).
       const bool fill = l_seq < tiles_total;
       int st_fill = st_it + NSTG - 1;
       if (st_fill >= NSTG) st_fill -= NSTG;
-      const bool late = fill && wave >= NW / 2;
+      const bool late = fill && (OLD_LATE ? wave < NW / 2 : wave >= NW / 2);
       if (fill && !late) {
         issue_dma(st_fill);
         ++issued;
       }
+      TR(2)
       compute(SWAPT, acc, lsx, lsq, st_it, late, st_fill);
+      TR(3) TR_COUNT(6)
       ++it;
       if (++st_it == NSTG) st_it = 0;
     }
@@ -637,6 +679,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
     } else {
       big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
     }
+    TR(4)
   };
 
   for (; seq < tiles_total; seq += G) {
@@ -651,6 +694,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       run_tile(IC<0>{}, IC<0>{});
     }
   }
+  TR_DUMP
 }
 
 int g_num_cu = 0;

@@ -69,7 +69,7 @@ template <> struct RefShift<IDF_F16> { static constexpr float v = 1.0f; };     /
 // and the end-of-tile wait leaves the loads issued in THIS tile in flight -- they have two tiles to land).
 // NW = waves per workgroup (64 queries each).  4: two independent workgroups per CU (their phases drift apart, which overlaps
 // one's MFMAs with the other's exponentials).  8: ONE workgroup per CU sharing every K / V^T tile among twice as many waves --
-// an LDS-DMA instruction holds its issuing wave ~180+ cycles (tools/ubench/dma_rate.hip), and with 11 KB per tile that is
+// an LDS-DMA instruction holds its issuing wave 55-72 cycles (tools/ubench/dma_mix.hip), and with 11 KB per tile that is
 // 2.75 instructions per wave and tile at NW = 4, 1.4 at NW = 8 (mode 2: +1 % in isolation, -3 % inside the forward; NW = 4 stays
 // the default -- profiles/r03_attn_ab*_B64.log, r03_shape_profile_B64_attn{1,2}.log).
 template <int DT, int NKS, int NMT, int VA, int NW = 4>

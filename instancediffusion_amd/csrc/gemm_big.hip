@@ -20,8 +20,11 @@
 // Round 2 (profiles/r02_*): the LDS-DMA pieces are inline assembly and the second half of the workgroup enqueues them from
 // the middle of its K-tile (fill schedule, see the K loop); split-K work items for grids that leave most CUs idle
 // (SPLIT); LayerNorm folded into the epilogue (IDF_EPI_LN_ROW / LN_COL) with the row statistics optionally summed in the
-// K loop itself (LNS); 128-wide tiles with three stages.  What bounds the K loop: tools/ubench/dma_rate.hip -- a wave moves
-// 5.6 B/clk from L2 into LDS, a CU 34 B/clk, the 256 x 320 tile needs 28.8 B/clk at 100 % MFMA.
+// K loop itself (LNS); 128-wide tiles with three stages.  What bounds the K loop (re-measured late in round 3, DESIGN.md
+// "What bounds the GEMM family"): not the fill rate -- a wave moves 14 B/clk from L2 into LDS, a CU 64 B/clk, the 256 x 320
+// tile needs 28.8 B/clk at 100 % MFMA (tools/ubench/dma_mix.hip; round 2's 5.6 / 34 were a ubench artefact) -- but power: the
+// kernel's mix of MFMAs, fragment reads and LDS-DMA sustains 1.11 PFLOP/s at 1.35-1.48 GHz even without any synchronisation
+// (tools/ubench/mfma_power.hip), pure MFMA 1.75-1.88 at 1.65-1.79 GHz (mfma_sustain.hip).
 // Round 3: (a) the geometries that were measured slower (two 4-wave workgroups per CU, the role-split ping-pong kernel, the
 // four-stage 32-deep ring, the end / spread fill schedules) left the library -- source snapshot
 // tools/ubench/archive/gemm_big_r02.hip, numbers profiles/r02_pp_*, r02_shape_profile_B64_fill_*; (b) fused q | k | v

@@ -1,3 +1,6 @@
+// SUPERSEDED by dma_mix.hip: the loop below updates its address with `pc % pieces` on 64-bit values (~180 cycles of VALU per
+// piece), which is what its per-wave numbers measured (5.6 B/clk; the real figure is 14 B/clk per wave, 64 B/clk per CU).  Kept
+// because profiles/r02_ubench_dma_rate.log and the round-2 analysis in DESIGN.md cite it.
 // How fast can one CU fill LDS from L2?  (the staging rate that bounds the GEMM / conv K-loop: a 256 x 320 tile needs
 // 28.8 B/clk/CU at 100 % MFMA).  One 512-thread workgroup per CU, every wave streams 1-KiB pieces of an L2-resident region:
 //   mode 0: global_load_lds_dwordx4 (LDS-DMA), window of W pieces in flight per wave

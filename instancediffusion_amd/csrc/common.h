@@ -30,6 +30,13 @@ template <> struct Elem<IDF_BF16> {
   static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
+  // The same MFMA as inline assembly with the accumulator pinned to the AGPR (AG) or the VGPR file: the 4-wave experiment of
+  // gemm_big.hip holds 320 accumulator registers per lane, more than either file, and the register allocator left to itself
+  // shuttles them between the files inside the K loop (640 v_accvgpr moves per K-tile).
+  template <bool AG> static __device__ __forceinline__ void mfma32_pin(u32x4 a, u32x4 b, f32x16& c) {
+    if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
   static constexpr unsigned ONES2 = 0x3f803f80u;                 // (1.0, 1.0)
   // acc += a.lo * b.lo + a.hi * b.hi on the packed pair (one VALU op per two elements)
   static __device__ __forceinline__ void dot2c(float& acc, unsigned a, unsigned b) {
@@ -46,6 +53,10 @@ template <> struct Elem<IDF_F16> {
   }
   static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  template <bool AG> static __device__ __forceinline__ void mfma32_pin(u32x4 a, u32x4 b, f32x16& c) {
+    if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   }
   static constexpr unsigned ONES2 = 0x3c003c00u;
   static __device__ __forceinline__ void dot2c(float& acc, unsigned a, unsigned b) {

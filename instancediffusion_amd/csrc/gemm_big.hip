@@ -44,7 +44,14 @@ namespace {
 
 __device__ __attribute__((aligned(128))) unsigned short idf_zero_page[64];   // zero-initialised device memory
 
-constexpr int WM = 64, TM = 2;                // wave tile: 64 rows x BN/2 columns
+// Wave tile: IDF_WAVE_ROWS rows x BN/2 columns.  64 (library): eight waves per workgroup, two per SIMD, 160 accumulator
+// registers per lane.  128 (experiment of tools/ubench/big_trace.hip, see DESIGN.md "What bounds the GEMM family"): four waves,
+// one per SIMD with the whole 512-register budget -- 9 fragment reads per 20 MFMAs instead of 7 per 10.
+#ifndef IDF_WAVE_ROWS
+#define IDF_WAVE_ROWS 64
+#endif
+constexpr int WM = IDF_WAVE_ROWS, TM = WM / 32;
+constexpr int NWAVES = 2 * 256 / WM;          // waves per 256-row workgroup tile (8 or 4)
 
 template <int I> struct IC { static constexpr int value = I; };
 template <int I, int N, int STEP, class F> __device__ __forceinline__ void static_for(F&& f) {
@@ -393,7 +400,7 @@ __device__ unsigned long long idf_big_trace_buf[4][8];
 #define TR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
 #define TR_COUNT(i) { tr_acc[i] += 1; }
 #define TR_DUMP { const int trb = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1);                     \
-    if (trb >= 0 && lane == 0 && (wave == 0 || wave == 4)) { for (int i = 0; i < 8; ++i) idf_big_trace_buf[trb * 2 + (wave >> 2)][i] = tr_acc[i]; } }
+    if (trb >= 0 && lane == 0 && (wave == 0 || wave == NWAVES / 2)) { for (int i = 0; i < 8; ++i) idf_big_trace_buf[trb * 2 + (wave ? 1 : 0)][i] = tr_acc[i]; } }
 #else
 #define TR_DECL
 #define TR(i)
@@ -405,9 +412,9 @@ __device__ unsigned long long idf_big_trace_buf[4][8];
 //   <256, {320,256}, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages); <256, 128, 64, 3>: 3 x 48 KB stages.
 template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false, bool STATS = false,
           bool GLU = false>
-__global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
+__global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
   constexpr int WN = BN / 2, TN = WN / 32;
-  constexpr int NW = BM / 32;                              // waves per workgroup (8 or 4)
+  constexpr int NW = NWAVES;                               // waves per workgroup: (BM / WM) x 2
   constexpr int RS = BKT;                                  // LDS row stride (elements): linear rows, no padding
   constexpr int CPR = BKT / 8;                             // 16-B chunks per row (8 or 4)
   constexpr int RPI = 64 / CPR;                            // rows moved by one LDS-DMA wave instruction (8 or 16)
@@ -529,6 +536,13 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
   constexpr bool OLD_LATE = BN == 320;
   constexpr int LATE_POS = OLD_LATE ? NPOS * 7 / 8 : NPOS / 2;
 #endif
+  // one wave per SIMD (NW == 4): there is no partner to hide a burst under, every wave enqueues one piece per position
+  constexpr bool SPREAD = NW == 4;
+#ifdef IDF_SPREAD_PPP
+  constexpr int PPP = IDF_SPREAD_PPP;                      // pieces per position of the spread fill (from position 0 on)
+#else
+  constexpr int PPP = (DPW + NPOS - 1) / NPOS;
+#endif
   // `late_fill`: this wave enqueues the next K-tile's LDS-DMA pieces from the MIDDLE of its MFMAs (see the K loop).
   // SWAPT: MFMA operands swapped (transposed-V tiles of the fused q | k | v projection): acc[a][b] then holds
   // D[m = b*32 + 8q + 4hi + e][n = a*32 + l31] -- a lane owns a channel, its registers run over tokens.
@@ -559,10 +573,20 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       static_for<0, TN, 1>([&](auto AI) {
         constexpr int a = decltype(AI)::value;
         constexpr int pos = ks * TN + a;
+        if constexpr (NW == 4) {
+          // accumulator fragments 0..15 (256 registers) pinned to the AGPR file, 16..19 to the VGPR file
+          static_for<0, TM, 1>([&](auto BI) {
+            constexpr int b = decltype(BI)::value;
+            constexpr bool AG = a * TM + b < 16;
+            if constexpr (SWAP) Elem<DT>::template mfma32_pin<AG>(af[cur][b], wf[cur][a], acc[a][b]);
+            else Elem<DT>::template mfma32_pin<AG>(wf[cur][a], af[cur][b], acc[a][b]);
+          });
+        } else {
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
-          if constexpr (SWAP) acc[a][b] = Elem<DT>::mfma32(af[cur][b], wf[cur][a], acc[a][b]);
-          else acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
+          for (int b = 0; b < TM; ++b) {
+            if constexpr (SWAP) acc[a][b] = Elem<DT>::mfma32(af[cur][b], wf[cur][a], acc[a][b]);
+            else acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
+          }
         }
         if constexpr (LNS && a == 0) {                      // row sums of the A fragments this k-step multiplies: 16 VALU ops
 #pragma unroll
@@ -573,7 +597,11 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
               Elem<DT>::dot2c(lsq[b], af[cur][b][w], af[cur][b][w]);
             }
         }
-        if constexpr (pos == LATE_POS - 1) {
+        if constexpr (SPREAD) {
+          if constexpr (pos * PPP < DPW) {
+            if (late_fill) static_for<pos * PPP, ((pos + 1) * PPP < DPW ? (pos + 1) * PPP : DPW), 1>([&](auto II) { issue_piece(st_fill, II); });
+          }
+        } else if constexpr (pos == LATE_POS - 1) {
           if (late_fill) static_for<0, DPW, 1>([&](auto II) { issue_piece(st_fill, II); });
         }
       });
@@ -639,7 +667,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       const bool fill = l_seq < tiles_total;
       int st_fill = st_it + NSTG - 1;
       if (st_fill >= NSTG) st_fill -= NSTG;
-      const bool late = fill && (OLD_LATE ? wave < NW / 2 : wave >= NW / 2);
+      const bool late = fill && (SPREAD || (OLD_LATE ? wave < NW / 2 : wave >= NW / 2));
       if (fill && !late) {
         issue_dma(st_fill);
         ++issued;
@@ -651,6 +679,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       if (++st_it == NSTG) st_it = 0;
     }
 
+    if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // inline-asm MFMAs: the compiler does not see their result latency
     // epilogue of tile seq: no workgroup barrier -- a wave that finishes its MFMAs early runs its epilogue while the other
     // wave of its SIMD is still in the K-loop
     float lnm[TM], lnr[TM];
@@ -668,7 +697,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_kernel_big(const CoreParams p,
       if constexpr (LNS) {
         // the statistics this wave summed in the K loop, parked in its own LDS slice (behind the ring) so that the
         // transposed epilogue can read the pair of ANY of the wave's 64 rows: [row][2], row = b*32 + l31
-        float* stw = reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 128;
+        float* stw = reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * (2 * WM);
         if (hi == 0) {
 #pragma unroll
           for (int b = 0; b < TM; ++b) *reinterpret_cast<f32x2*>(stw + 2 * (b * 32 + l31)) = f32x2{lnm[b], lnr[b]};
@@ -721,7 +750,7 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
     if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT, false, GLU>(p, s, 1);
   }
   void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS, GLU>;
-  constexpr int smem = NSTG * (BM + BN) * BKT * 2 + ((VT && LNS) ? 8 * 128 * 4 : 0);
+  constexpr int smem = NSTG * (BM + BN) * BKT * 2 + ((VT && LNS) ? NWAVES * 2 * WM * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -736,7 +765,7 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   const int tiles = q.full_items + (tiles_all - q.full_items) * splitk;   // work items
   const int slots = num_cu();
   const int grid = tiles < slots ? tiles : slots;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(BM * 2), smem, s, q, tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), smem, s, q, tiles);
   return idf_launch_status();
 }
 

@@ -23,7 +23,7 @@ __global__ void checksum_kernel(const unsigned* x, size_t n, unsigned long long*
   atomicAdd(out, acc);
 }
 
-struct Shape { const char* name; int M, N, K; int epi; bool conv; int B, H, Cin; };
+struct Shape { const char* name; int M, N, K; int epi; bool conv; int B, H, Cin; int stride = 1, up = 0; };
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
@@ -63,13 +63,17 @@ int main(int argc, char** argv) {
       {"conv 64^2 320 bias", 0, 320, 0, IDF_EPI_BIAS, true, 64, 64, 320},
       {"conv 32^2 640 bias", 0, 640, 0, IDF_EPI_BIAS, true, 64, 32, 640},
       {"conv 16^2 1280 bias", 0, 1280, 0, IDF_EPI_BIAS, true, 64, 16, 1280},
+      {"conv 32^2 640 stride 2", 0, 640, 0, IDF_EPI_BIAS, true, 64, 32, 640, 2, 0},
+      {"conv 16^2->32^2 1280 up", 0, 1280, 0, IDF_EPI_BIAS, true, 64, 16, 1280, 1, 1},
+      {"conv 64^2 640->320 +res", 0, 320, 0, IDF_EPI_BIAS | IDF_EPI_RES, true, 64, 64, 640},
   };
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (const Shape& sh : shapes) {
     CoreParams p{};
     if (sh.conv) {
-      p.Ho = sh.H; p.Wo = sh.H; p.Hin = sh.H; p.Win = sh.H; p.Cin = sh.Cin; p.stride = 1; p.up = 0;
-      p.M = sh.B * sh.H * sh.H; p.K = 9 * sh.Cin; p.lda = sh.Cin; p.ldw = 9 * sh.Cin; p.rows_per_batch = sh.H * sh.H;
+      const int hup = sh.H << sh.up;
+      p.Ho = (hup - 1) / sh.stride + 1; p.Wo = p.Ho; p.Hin = sh.H; p.Win = sh.H; p.Cin = sh.Cin; p.stride = sh.stride; p.up = sh.up;
+      p.M = sh.B * p.Ho * p.Wo; p.K = 9 * sh.Cin; p.lda = sh.Cin; p.ldw = 9 * sh.Cin; p.rows_per_batch = p.Ho * p.Wo;
     } else {
       p.M = sh.M; p.K = sh.K; p.lda = sh.K; p.ldw = sh.K; p.rows_per_batch = sh.M;
     }

@@ -206,7 +206,13 @@ def measure_roofline(engine, batch, fuser_on=True):
                 algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
                 algorithmic_mbytes_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2), measured_at_batch=batch,
                 forward_breakdown_ms={k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
-                forward_total_ms=round(total_ms, 3))
+                forward_total_ms=round(total_ms, 3),
+                # context for `frac`, NOT measured in this run: what the chip sustains under its power limit, from the torch-free
+                # micro-benchmarks of round 3 (a kernel issuing nothing but bf16 MFMAs; the same stream plus this kernel family's
+                # LDS fragment reads and LDS-DMA pieces per MFMA, without any synchronisation)
+                peak_context=dict(spec_peak=PEAK_MFMA_TF, sustained_mfma_only=1876.0, sustained_mfma_plus_kloop_operand_traffic=1115.0,
+                                  unit="TFLOP/s", source="profiles/r03_ubench_mfma_sustain.log, profiles/r03_ubench_mfma_power.log "
+                                                          "(tools/ubench/mfma_sustain.hip, mfma_power.hip)"))
 
 
 def cpu_baseline(cfg, sd, host_inputs, budget_s=25.0):

@@ -72,6 +72,27 @@ template <> struct RefShift<IDF_F16> { static constexpr float v = 1.0f; };     /
 // an LDS-DMA instruction holds its issuing wave 55-72 cycles (tools/ubench/dma_mix.hip), and with 11 KB per tile that is
 // 2.75 instructions per wave and tile at NW = 4, 1.4 at NW = 8 (mode 2: +1 % in isolation, -3 % inside the forward; NW = 4 stays
 // the default -- profiles/r03_attn_ab*_B64.log, r03_shape_profile_B64_attn{1,2}.log).
+// Optional per-segment cycle trace (a second library build with -DIDF_ATTN_TRACE, read through idf_attn_trace_read by
+// tools/ubench/attn_harness.hip; the shipped library has none of it): s_memtime deltas of wave 0 of the first and of a middle
+// workgroup, summed over the common-path tiles.  Segments: 0 LDS-DMA issue, 1 K.Q^T MFMA issue (both query groups),
+// 2 exp + pack of group 0, 3 P.V of group 0, 4 exp + pack of group 1, 5 next tile's K fragment reads, 6 P.V of group 1,
+// 7 vmcnt wait + workgroup barrier, 8 overflow check, 9 number of tiles.
+#ifdef IDF_ATTN_TRACE
+__device__ unsigned long long idf_attn_trace_buf[2][10];
+#define ATR_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ATR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
+#define ATR_RESET { tr_last = __builtin_readcyclecounter(); }
+#define ATR_COUNT(i) { tr_acc[i] += 1; }
+#define ATR_DUMP { const int trb = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1);                     \
+    if (trb >= 0 && tid == 0) { for (int i = 0; i < 10; ++i) idf_attn_trace_buf[trb][i] = tr_acc[i]; } }
+#else                      // (empty BLOCKS, not empty macros: `if constexpr (..) ATR(1)` must not swallow the next statement)
+#define ATR_DECL
+#define ATR(i) {}
+#define ATR_RESET {}
+#define ATR_COUNT(i) {}
+#define ATR_DUMP {}
+#endif
+
 template <int DT, int NKS, int NMT, int VA, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, const int nqb, const int xcd_order) {
   constexpr int DCH = 2 * NKS - 1;                 // 16-B chunks per K row
@@ -254,6 +275,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
       dst[st][NKS - 1] = *reinterpret_cast<const u32x4*>(last);
     }
   };
+  ATR_DECL
   f32x16 s[2][2];                                    // [query group][kv half]
   u32x4 pk[2][4];                                    // packed P: [group][16-key step]
   u32x4 kf[2][NKS];                                  // K fragments of the CURRENT tile, read one tile ahead
@@ -342,16 +364,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
     asm volatile("" : "+v"(hi_o));
     qk(0);
     qk(1);
+    if constexpr (!EXACT) ATR(1)
     if constexpr (EXACT) {
       // keys beyond n in a tail tile are clamped duplicates of a valid key: they cannot raise the max
       rebase_scores(0, t == 0);
       rebase_scores(1, t == 0);
     }
     unsigned acc = exp_pack(0);
+    if constexpr (!EXACT) ATR(2)
     pv(0, t % VST);
+    if constexpr (!EXACT) ATR(3)
     acc |= exp_pack(1);
+    if constexpr (!EXACT) ATR(4)
     load_kf(kf, (t + 1) % 3, hi_o);                  // next tile's K fragments (a stale stage after the last tile: unused)
+    if constexpr (!EXACT) ATR(5)
     pv(1, t % VST);
+    if constexpr (!EXACT) ATR(6)
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -446,6 +474,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
       const size_t kstep = (size_t)KVT * p.ldk[0] * 2;
       for (; t + 2 < F0; ++t) {
         // Every wave passed the barrier that ended tile t-1: K(t+1) and V^T(t) are visible, K(t-1) / V^T(t-1) are dead.
+        ATR_RESET
         unsigned short* kdst = Ks + ((t + 2) % 3) * KSZ;
         unsigned short* vdst = Vs + ((t + VA) % VST) * VSZ;
 #pragma unroll
@@ -458,9 +487,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
             dma16_sv(vptr, voff0[j], lds_addr(vdst + (vwave + NW * j) * 512));
         kptr += kstep;
         vptr += KVT * 2;
+        ATR(0)
         const unsigned acc = tile(FalseT{}, t);
         end_tile(true);
+        ATR(7)
         after_tile(acc);
+        ATR(8) ATR_COUNT(9)
       }
     }
     // ---- remaining tiles (segment change, tail tiles, end of the key range; every tile of the fallback pass)
@@ -482,6 +514,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
     exact_all = true;                               // workgroup-uniform: all four waves redo the block
   }
 
+  ATR_DUMP
   // ---- normalise and store.  o[g][mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31 of group g.
   // row e = D of O^T holds the denominator: tile D/32, register 4*((D%32)/8) of the hi = 0 lanes.
   // A lane owns ONE query row in 8-byte pieces: stored directly that is DCH 8-B stores per lane at a 2*ldo-byte lane
@@ -543,6 +576,12 @@ int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef IDF_ATTN_TRACE
+extern "C" int idf_attn_trace_read(unsigned long long* host /* [2][10] */) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(idf_attn_trace_buf), sizeof(idf_attn_trace_buf));
+}
+#endif
 
 int idf_launch_attn4(const AttnParams& p, int B, int dtype, hipStream_t s) {
   if (p.d != 24 && p.d != 40 && p.d != 56) return IDF_ATTN2_UNSUPPORTED;

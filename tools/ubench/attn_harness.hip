@@ -4,6 +4,9 @@
 // minutes of tools/attn_ab.py (Python + torch import).  The library is dlopen'ed by path, so two builds can be compared in one run.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/ubench/attn_harness.hip -o tools/ubench/attn_harness -ldl
 // Run:   tools/ubench/attn_harness instancediffusion_amd/libidf_gfx950.so [batch=64] [modes=1,2,0] [other.so ...]
+// A library built with -DIDF_ATTN_TRACE on attention4.hip (instancediffusion_amd/csrc/build.sh has the flags; link the other
+// objects unchanged) additionally exports idf_attn_trace_read: the harness then prints the s_memtime cycles per segment of the
+// d = 40 kernel's common-path tile.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>
@@ -32,6 +35,7 @@ struct Lib {
   void* h; std::string path;
   int (*attention)(const idf_attn_args*, void*);
   int (*set_tuning)(int, int);
+  int (*trace_read)(unsigned long long*);          // only in a -DIDF_ATTN_TRACE build of the library
 };
 
 struct Shape { const char* name; int N, d, n0, n1; };
@@ -48,6 +52,7 @@ int main(int argc, char** argv) {
     if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", argv[i], dlerror()); return 2; }
     l.attention = (int (*)(const idf_attn_args*, void*))dlsym(l.h, "idf_attention");
     l.set_tuning = (int (*)(int, int))dlsym(l.h, "idf_set_tuning");
+    l.trace_read = (int (*)(unsigned long long*))dlsym(l.h, "idf_attn_trace_read");
     if (!l.attention || !l.set_tuning) { fprintf(stderr, "%s: missing symbols\n", argv[i]); return 2; }
     libs.push_back(l);
   }
@@ -103,6 +108,20 @@ int main(int argc, char** argv) {
         unsigned long long cs = 0; hipMemcpy(&cs, csum, 8, hipMemcpyDeviceToHost);
         printf("%-12s d=%-3d keys %4d+%-3d  lib %zu mode %d: rc %d  %8.1f us  %7.1f TF  checksum %016llx\n", sh.name, sh.d, sh.n0, sh.n1, li, m, rc,
                best * 1e3, flops / (best * 1e-3) / 1e12, cs);
+        if (libs[li].trace_read && sh.d == 40 && sh.n0 > 77 && m >= 1) {
+          unsigned long long tr[2][10];
+          if (libs[li].trace_read(&tr[0][0]) == 0) {
+            const char* seg[9] = {"dma", "qk", "exp0", "pv0", "exp1", "kfrag", "pv1", "wait+bar", "check"};
+            for (int g = 0; g < 2; ++g) {
+              const double nt = (double)tr[g][9];
+              if (nt == 0) continue;
+              double tot = 0;
+              printf("    %s wave 0, per common-path tile (%.0f tiles; 896 cycles of MFMA each):", g ? "wgM" : "wg0", nt);
+              for (int i = 0; i < 9; ++i) { printf(" %s %.0f", seg[i], tr[g][i] / nt); tot += tr[g][i] / nt; }
+              printf(" = %.0f\n", tot);
+            }
+          }
+        }
         libs[li].set_tuning(IDF_TUNE_ATTN2, 1);
       }
   }

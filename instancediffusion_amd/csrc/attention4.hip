@@ -80,8 +80,11 @@ template <> struct RefShift<IDF_F16> { static constexpr float v = 1.0f; };     /
 #ifdef IDF_ATTN_TRACE
 __device__ unsigned long long idf_attn_trace_buf[2][10];
 #define ATR_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define ATR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
-#define ATR_RESET { tr_last = __builtin_readcyclecounter(); }
+// -DIDF_ATTN_TRACE=2: two time stamps per tile only (segments 1 = top of the tile .. K.Q^T MFMAs issued, 7 = the rest): the full
+// set costs the kernel 46 % (every stamp drains lgkmcnt), this one a few per cent
+#define ATR_ON(i) (IDF_ATTN_TRACE != 2 || (i) == 1 || (i) == 7)
+#define ATR(i) { if constexpr (ATR_ON(i)) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; } }
+#define ATR_RESET { if constexpr (IDF_ATTN_TRACE != 2) tr_last = __builtin_readcyclecounter(); }
 #define ATR_COUNT(i) { tr_acc[i] += 1; }
 #define ATR_DUMP { const int trb = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1);                     \
     if (trb >= 0 && tid == 0) { for (int i = 0; i < 10; ++i) idf_attn_trace_buf[trb][i] = tr_acc[i]; } }

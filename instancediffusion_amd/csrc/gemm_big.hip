@@ -433,6 +433,19 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
   // [x*G/8, (x+1)*G/8) of the n-fastest list, so tiles sharing an activation m-tile / weight n-tile share an L2.
   const int slot = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int tiles_n = p.N / BN;
+  // Tile walk.  Strided (rounds 1-3): workgroup slot s takes tiles s, s + G, ... -- the eight workgroups that share an
+  // activation m-tile fetch it at the same moment, one misses to HBM and all eight wait for that line.  Chunked (round 4,
+  // tile_walk = 1, unsplit launches): slot s takes the CONTIGUOUS tiles [s q + min(s, r), ...) of the n-fastest list, so a
+  // workgroup walks the n-tiles of ONE m-tile back to back: the activation rows come from HBM once and from L2 for the
+  // other tiles_n - 1 tiles, and the weight n-tile every workgroup streams at a given moment is the same one (L2-hot).
+  // Either walk runs every tile through the same arithmetic: outputs are bit-identical.
+  int seq_step = G, seq_end = tiles_total, seq0 = slot;
+  if (!SPLIT && p.tile_walk == 1 && tiles_total > G) {
+    const int q = tiles_total / G, r = tiles_total - q * G;
+    seq0 = slot * q + min(slot, r);
+    seq_end = seq0 + q + (slot < r ? 1 : 0);
+    seq_step = 1;
+  }
   // split-K (p.splitk > 1): work item seq = tile * splitk + slice covers K-tiles [slice * nk, (slice + 1) * nk) of its tile
   // and leaves fp32 partials in p.ws[slice][M][N] (reduced + epilogue by splitk_reduce_kernel)
   // Hybrid (round 3): a tile count that is not close to a whole number of 256-CU rounds used to send the launch to the 128^2
@@ -533,8 +546,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
     if (CONV) { ci0 += BKT; if (ci0 >= p.Cin) { ci0 = 0; ++tap; } }
     if (++l_kt == l_nk) {
       l_kt = 0;
-      l_seq += G;
-      if (l_seq < tiles_total) setup_loader(l_seq);
+      l_seq += seq_step;
+      if (l_seq < seq_end) setup_loader(l_seq);
     }
   };
   auto issue_dma = [&](int stage) {                       // enqueue the whole K-tile into `stage`, then advance
@@ -630,15 +643,28 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
     if (late_fill) { advance_loader(); ++issued; }
   };
 
-  int seq = slot;
-  if (seq >= tiles_total) return;
+  int seq = seq0;
+  if (seq >= seq_end) return;
+  // De-phasing (round 4): a persistent launch whose tiles all cost the same runs its 256 workgroups in lock step, so every
+  // CU reaches its epilogue at the same moment: the store burst of a round (160 KB per CU, 41 MB per round) then meets an
+  // HBM that idled through the K loops, and the waves sit in store-issue back-pressure (cycle trace of `M262144 N2560 K320`:
+  // 19-20 k cycles of epilogue per tile for 20 stores per wave, ~4 TB/s of writes in bursts, 1.9 TB/s on average).  With
+  // p.dephase = P > 1 the workgroups of every XCD start in P groups, group g delayed by g / P of one tile's estimated
+  // duration, so at any moment only ~1 / P of the CUs are in their store burst.  The delay costs (P - 1) / P of a tile at
+  // the start of the launch; the dispatcher asks for it on launches of >= 8 rounds only.
+  if (p.dephase > 1) {
+    const int ph = (int)(blockIdx.x >> 3) % p.dephase;
+    const int units = ph * p.dephase_units / p.dephase;       // units of 1024 cycles
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   l_seq = seq;
   setup_loader(l_seq);
   // prologue: NSTG-1 K-tiles of the flattened (tile, k) stream in flight
 #pragma unroll
   for (int j = 0; j < NSTG - 1; ++j)
-    if (l_seq < tiles_total) { issue_dma(j); ++issued; }
+    if (l_seq < seq_end) { issue_dma(j); ++issued; }
   int it = 0, st_it = 0;                                  // K-tile consumed next and its ring stage
+  int young_stores = 0;                                   // lower bound of the stores issued since the last LDS-DMA piece
   TR_DECL
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
@@ -668,6 +694,20 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
       // wait followed by a barrier.  In steady state the NSTG-2 younger K-tiles stay in flight across the barrier
       // (counted wait; VM ops retire in order); at the tail of the stream fewer are outstanding -> wait for all.
       if (NSTG > 2 && issued - it == NSTG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * DPW) : "memory");
+      else if (NSTG == 2 && kt == 0 && young_stores > 0) {
+        // First K-tile behind an epilogue (round 4): its LDS-DMA pieces were enqueued during the previous tile's last
+        // K-tile, i.e. BEFORE that tile's epilogue stores, and vector memory operations retire in order -- so "at most
+        // `young_stores` operations outstanding" already means the pieces have landed, while vmcnt(0) would also wait for
+        // the whole store burst to reach L2 (cycle trace at K = 320: 5-7 k cycles per tile).  young_stores is a LOWER bound
+        // on the store instructions the previous epilogue issued (0 unless that tile had all 256 rows: a wave without a
+        // valid row branches around its stores).
+        if (young_stores >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (young_stores >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (young_stores >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (young_stores >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (young_stores >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TR(0)
       __builtin_amdgcn_s_barrier();                       // ... and every wave has finished reading the stage refilled below
@@ -685,7 +725,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
       // the older wave's MFMAs: K-tile period 3770 -> 3190 cycles at K = 5120; in time -2...-9 % per launch
       // (profiles/r03_big_sched_ab.log), less than in cycles because the chip is power-limited here: the shader clock falls as
       // the pipe fills (clock x pipe-busy ~ constant ~ 1.0-1.2 GHz across all schedules, r03_big_trace_variants*.log).
-      const bool fill = l_seq < tiles_total;
+      const bool fill = l_seq < seq_end;
       int st_fill = st_it + NSTG - 1;
       if (st_fill >= NSTG) st_fill -= NSTG;
       const bool late = fill && (SPREAD || (OLD_LATE ? wave < NW / 2 : wave >= NW / 2));
@@ -733,9 +773,17 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
       big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
     }
     TR(4)
+    // store instructions this wave just issued, at least (see the first K-tile's wait above)
+    young_stores = 0;
+    if (p.epi_vmcnt && (tile / tiles_n) * BM + BM <= p.M) {
+      if constexpr (SWAP) young_stores = 2 * TN * TM;
+      else if constexpr (SPL) young_stores = 4 * TN * TM;
+      else if constexpr (GLU) young_stores = TN * TM;
+      else young_stores = (epi & IDF_EPI_GEGLU) ? TN * TM : ((epi & IDF_EPI_OUT_F32) ? 4 * TN * TM : 2 * TN * TM);
+    }
   };
 
-  for (; seq < tiles_total; seq += G) {
+  for (; seq < seq_end; seq += seq_step) {
     if constexpr (VT) {
       // fused q | k | v projection: this tile's columns belong to V -> swapped operands, transposed store (workgroup-uniform)
       if ((seq % tiles_n) * BN >= p.vt_col0) run_tile(IC<1>{}, IC<0>{});
@@ -759,6 +807,27 @@ int num_cu() {
     g_num_cu = n;
   }
   return g_num_cu;
+}
+
+// Schedule settings of the persistent kernel (process-global, read once from the environment; idf_set_tuning may override).
+struct BigSched { int walk, dephase, dephase_min_rounds, dephase_epi_cycles, epi_vmcnt; };
+BigSched& big_sched() {
+  static BigSched sc = [] {
+    auto env = [](const char* name, int dflt, int lo, int hi) {
+      const char* e = getenv(name);
+      if (!e) return dflt;
+      const int v = atoi(e);
+      return (v < lo || v > hi) ? dflt : v;
+    };
+    BigSched c;
+    c.walk = env("IDF_BIG_WALK", 0, 0, 1);
+    c.dephase = env("IDF_BIG_DEPHASE", 0, 0, 16);
+    c.dephase_min_rounds = env("IDF_BIG_DEPHASE_MIN_ROUNDS", 8, 1, 1 << 20);
+    c.dephase_epi_cycles = env("IDF_BIG_DEPHASE_EPI", 6000, 0, 1 << 20);
+    c.epi_vmcnt = env("IDF_BIG_EPIVM", 0, 0, 1);
+    return c;
+  }();
+  return sc;
 }
 
 template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false, bool STATS = false, bool GLU = false>
@@ -786,6 +855,17 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   const int tiles = q.full_items + (tiles_all - q.full_items) * splitk;   // work items
   const int slots = num_cu();
   const int grid = tiles < slots ? tiles : slots;
+  {                                                       // schedule knobs (all bit-identical; see the kernel)
+    const BigSched& sc = big_sched();
+    const int rounds = (tiles + slots - 1) / slots;
+    q.tile_walk = (!SPLIT && sc.walk) ? 1 : 0;
+    q.epi_vmcnt = sc.epi_vmcnt;
+    q.dephase = 0; q.dephase_units = 0;
+    if (!SPLIT && sc.dephase > 1 && rounds >= sc.dephase_min_rounds) {
+      q.dephase = sc.dephase;
+      q.dephase_units = (q.kt_full * 3400 + sc.dephase_epi_cycles) / 1024;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), smem, s, q, tiles);
   return idf_launch_status();
 }

@@ -30,6 +30,10 @@ struct CoreParams {
   // out_stats by-product of the persistent kernel: every wave leaves (mean, M2) of the BN/2 output columns it owns of a row
   // in stat_parts[(m * parts + tile_n * 2 + wn) * 2 ..] (fp32, workspace); stats_finalize merges the `parts` slots of a row
   float* stat_parts; int parts;
+  // persistent-kernel schedule (round 4; every setting computes the same bits): tile_walk 0 = strided, 1 = chunked;
+  // dephase = P start groups per XCD (0 / 1: off), dephase_units = one tile's estimated duration in units of 1024 cycles;
+  // epi_vmcnt = 1: the first K-tile behind an epilogue waits with a counted vmcnt (the epilogue's stores drain under it)
+  int tile_walk; int dephase; int dephase_units; int epi_vmcnt;
 };
 
 constexpr int BK = 64;

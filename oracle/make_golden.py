@@ -200,6 +200,47 @@ def gen_case(tag: str, cfg_name: str, variant: str, latent: int, n_boxes: int, b
 
 
 @torch.no_grad()
+def gen_plms_mask_case(tag="tiny_box_plms_mask", cfg_name="test_box.yaml", variant="tiny", latent=16, n_boxes=3, batch=2, S=5):
+    """PLMSSampler.sample(mask=, x0=) -- the inpainting blend of plms.py:99-104 (``img = q_sample(x0, ts) * mask +
+    (1 - mask) * img`` in front of every step) on the unmodified reference.  q_sample draws its noise from the global RNG
+    (ldm.py:18); the draw is made here, recorded, and handed to the reference's own q_sample through its ``noise``
+    argument, so a test can replay the same noise on any device.  Inputs are those of ``tiny_box`` (same generator)."""
+    print(f"[golden] {tag}", flush=True)
+    cfg = load_cfg(cfg_name, variant)
+    model, gi, diffusion, schema, synth = build(cfg)
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = torch.Generator().manual_seed(1234)
+    bx = synth.random_boxes(n_boxes, g)
+    gb = synth.make_grounding_batch(batch, bx, g, with_scribbles=False, with_polygons=False, with_segs=False, seg_size=512)
+    x = torch.randn(batch, 4, latent, latent, generator=g)
+    context = torch.randn(batch, 77, 768, generator=g)
+    uc = torch.randn(batch, 77, 768, generator=g)
+    g2 = torch.Generator().manual_seed(4321)
+    mask = (torch.rand(batch, 1, latent, latent, generator=g2) > 0.5).float()
+    x0 = torch.randn(batch, 4, latent, latent, generator=g2)
+    noises = []
+    real_q = diffusion.q_sample
+
+    def q_sample(x_start, t, noise=None):
+        n = torch.randn(x_start.shape, generator=g2)
+        noises.append(n.clone())
+        return real_q(x_start, t, noise=n)
+    diffusion.q_sample = q_sample
+    m2 = deepcopy(model)
+    m2.grounding_tokenizer_input = gi
+    patch_first_conv(m2, synth.synth_first_conv_sd())
+    sampler = PLMSSampler(diffusion, m2, alpha_generator_func=partial(ref_alpha_generator, type=[1, 0, 0]),
+                          set_alpha_scale=ref_set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=context, grounding_input=gi.prepare(gb))
+    out = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=x0).clone()
+    os.chdir(REF)
+    meta = dict(tag=tag, cfg=cfg_name, variant=variant, alpha_type=[1, 0, 0], latent=latent, n_boxes=int(bx.shape[0]), batch=batch,
+                boxes="rand", with_scribbles=False, with_polygons=False, with_segs=False, S=S, mis=0.0, n_inst=0, seg_size=512,
+                x_fp=fp(x), ctx_fp=fp(context))
+    torch.save(dict(meta=meta, plms_masked=out, mask=mask, x0=x0, noises=torch.stack(noises)), os.path.join(GOLD, f"{tag}.pt"))
+
+
+@torch.no_grad()
 def gen_full_s50(tag="full_box_s50", S=50, mis=0.36, n_inst=8, alpha_type=(0.8, 0.0, 0.2)):
     """The BASELINE headline trajectory on the headline model: the UNMODIFIED reference ``PLMSSamplerInst``
     (plms_instance.py:59-158) driving the full 1.228 B-parameter UNet, B=1, 64x64 latent, S=50 (inference.py:64),
@@ -695,6 +736,8 @@ def main():
         gen_ckpt_case()
     if args.only in ("all", "clip"):
         gen_clip_case()
+    if args.only in ("all", "plms_mask"):
+        gen_plms_mask_case()
     print("done")
 
 

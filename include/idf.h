@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IDF_ABI_VERSION 3
+#define IDF_ABI_VERSION 4
 
 enum { IDF_BF16 = 0, IDF_F16 = 1 };                 /* 16-bit storage / MFMA input type */
 enum { IDF_E_ARG = -1, IDF_E_ALIGN = -2, IDF_E_UNSUPPORTED = -3 };
@@ -106,13 +106,40 @@ typedef struct {
   /* Fused q | k | v projection (attention.py:168-172 -- to_q, to_k, to_v read the same LayerNorm output): with vt_out != NULL
    * the output columns n >= vt_col0 are stored TRANSPOSED, vt_out[(n - vt_col0) * ld_vt + m] (16-bit; ld_vt >= M, % 8 == 0)
    * -- the V^T[channel][token] image idf_attention consumes -- and `out` holds the first vt_col0 columns only.  Epilogue:
-   * BIAS and / or LN_ROW only (LN_ROW's beta term of a transposed column is bias[n] as for the others), batch 1, no
-   * out_stats; self-normalising LN_ROW additionally needs ln_stats_out.  One launch of the persistent kernel when
+   * exactly LN_ROW (+ BIAS, which LN_ROW requires: the beta term of a transposed column is bias[n] as for the others);
+   * anything else is IDF_E_ARG before any launch.  Batch 1, no out_stats; self-normalising LN_ROW additionally needs
+   * ln_stats_out.  One launch of the persistent kernel when
    * N % 320 == vt_col0 % 320 == 0 and M % 16 == 0 (its transposed tiles run the same K loop with the MFMA operands swapped);
    * any other shape runs as the two GEMMs this replaces. */
   void* vt_out; int ld_vt; int vt_col0;
 } idf_gemm_args;
 int idf_gemm(const idf_gemm_args* a, void* stream);
+
+/* ---- fused GEGLU feed-forward (attention.py:36-63 GEGLU / FeedForward; call sites :309 `x + tanh(alpha_dense) *
+ * ff(norm2(x))` and :337 `ff(norm3(x)) + x`):  out = x + [gate[0] *] ( W2 . (value * gelu(gate)) + b2 ),
+ * (value | gate) = LN(x) . W1^T + b1 -- ONE launch, the 4C-wide activated intermediate never leaves the CU (as two idf_gemm
+ * calls it is written to and read back from HBM).  LayerNorm is folded as in IDF_EPI_LN_ROW: w1 carries gamma, ln_stats the
+ * rows' (mu, rstd), cd the constants.  Operand images (packed once by the caller):
+ *   w1  [8C][C]   rows interleaved [16 value | 16 gate] per 32 (IDF_EPI_GEGLU_P32's packing), ld = ldw1;
+ *   cd  f32 [8C/64][128]: per 64 packed rows c[64] (row sums of the 16-bit w1) | d[64] (W1.beta + b1, packed like the rows);
+ *   w2p [C][4C]   W2 with the k index permuted inside every 16-group: w2p[n][16 g + p] = W2[n][16 g + perm[p]],
+ *                 perm = {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15}, ld = ldw2;
+ * out may alias x.  Supported: C == 320 (the 64 x 64-latent blocks), M % 128 == 0; otherwise IDF_E_UNSUPPORTED and the
+ * caller runs the two idf_gemm calls this replaces.  Results equal theirs up to the fp32 summation order of the second
+ * product (the intermediate is rounded to the 16-bit type in both).                                                     */
+typedef struct {
+  const void* x; int ldx;
+  const float* ln_stats;
+  const void* w1; int ldw1;
+  const float* cd;
+  const void* w2p; int ldw2;
+  const float* b2;
+  const float* gate;                  /* device scalar, or NULL (= 1) */
+  void* out; int ldo;
+  int M, C;
+  int dtype;
+} idf_mlp_args;
+int idf_mlp_geglu(const idf_mlp_args* a, void* stream);
 
 /* (mu, rstd) of every row of a 16-bit [M, C] matrix (exact two-pass, fp32): stats[m] = (mean, 1/sqrt(var + eps)).
  * The stand-alone producer of `ln_stats` (idf_gemm's out_stats is the fused one).  C % 8 == 0, C <= 1536.          */

@@ -393,7 +393,13 @@ std::atomic<long long> idf_stat_attn2_launches{0};
 
 int g_attn2_mode = -2;
 int idf_attn2_mode() {
-  if (g_attn2_mode == -2) { const char* e = getenv("IDF_ATTN2"); g_attn2_mode = e ? atoi(e) : IDF_ATTN2_DEFAULT; }
+  if (g_attn2_mode == -2) {
+    // the environment may hold a value of an older ABI (modes 4..14 named kernels that left the library): out of range = default,
+    // the same range idf_set_tuning accepts
+    const char* e = getenv("IDF_ATTN2");
+    const int v = e ? atoi(e) : IDF_ATTN2_DEFAULT;
+    g_attn2_mode = (v < 0 || v > 3) ? IDF_ATTN2_DEFAULT : v;
+  }
   return g_attn2_mode;
 }
 int idf_attn2_set_mode(int v) { const int prev = idf_attn2_mode(); g_attn2_mode = v; return prev; }

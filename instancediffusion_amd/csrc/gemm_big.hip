@@ -85,12 +85,51 @@ __device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigne
 // finalize kernel replaces the pass that re-read the whole output (65 of them per forward in round 2).
 // GLU: the kernel instantiation that serves ONLY period-32 GEGLU launches on the 5-fragment (320-wide) wave tile: compiled with
 // nothing but that branch -- carrying it as a run-time branch in the other 320-wide kernels cost them ~290 spilled VGPRs.
+// ---- coalesced epilogue accesses (round 4).  After the v_permlane32_swap exchange a lane owns 16 consecutive columns of ITS
+// row, so a 16-B store / residual load instruction touches 32 different rows in 64 separate 16-B pieces: 64 requests per
+// instruction, and the CU's vector-memory path retires about one request per cycle -- 8 waves x 20 stores x 64 requests =
+// 10 k cycles per tile, which IS the 13-20 k-cycle epilogue of the cycle traces (52 k with the residual loads), whatever the
+// HBM does (de-phasing the workgroups changed nothing: profiles/r04_big_sched_walk_dephase_epivm.log).  Now a 32 x 32 fragment
+// (2 KB of 16-bit values) goes through a wave-private 2-KB LDS slot -- the 16 KB the two 72-KB ring stages leave of the CU's
+// 160 KB -- and is stored (the residual: loaded) with 4 adjacent lanes on the 64 contiguous bytes of one row: 16 requests per
+// instruction.  Same values, same arithmetic, same instruction count; wave-private, so still no workgroup barrier.
+// Slot image: [32 rows][64 B], 16-B piece ^= f(row) with f = ((b2 ^ b3) << 1) | (b1 ^ b3 ^ b4) of the row's bits: both access
+// patterns (lane = row with two pieces: "math layout"; 4 lanes per row: "store layout") are bank-conflict-free for
+// ds_read_b128's 16-lane groups and ds_write_b128's 8-lane groups.
+#ifndef IDF_EPI_STAGE
+#define IDF_EPI_STAGE 0
+#endif
+__device__ __forceinline__ int stg_f(int row) {
+  return ((((row >> 2) ^ (row >> 3)) & 1) << 1) | (((row >> 1) ^ (row >> 3) ^ (row >> 4)) & 1);
+}
+// piece `pc` (0..3) of row `row` of the slot
+__device__ __forceinline__ u32x4* stg_at(char* stg, int row, int pc) {
+  return reinterpret_cast<u32x4*>(stg + row * 64 + ((pc ^ stg_f(row)) << 4));
+}
+
 template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false, bool STATS = false, bool GLU = false>
 __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int slice, int tiles_n, int wm,
-                                             int wn, int l31, int hi, float gate, const float* lnm = nullptr,
+                                             int wn, int l31_in, int hi_in, float gate, char* stg_in, const float* lnm = nullptr,
                                              const float* lnr = nullptr) {
   constexpr int WN = BN / 2;
+  constexpr bool STG = IDF_EPI_STAGE != 0;
   const int epi = p.epi;
+  // opaque copies: everything the epilogue derives from the lane id (row / column offsets, slot addresses) is then computed
+  // HERE, per tile, instead of being hoisted out of the tile loop and kept alive -- or spilled -- across the K loop
+  int l31 = l31_in, hi = hi_in;
+  asm volatile("" : "+v"(l31), "+v"(hi));
+  char* const stg = stg_in;
+  const int sl_row = (l31 + 32 * hi) >> 2, sl_pc = l31 & 3;       // store layout: lane -> row sl_row (+ 16), piece sl_pc
+  // 32 rows x 64 B from the slot to rows m_base.. of a 16-bit matrix (column c0), 16 rows x 64 contiguous bytes per instruction
+  auto stg_store64 = [&](unsigned short* base, int ld, int m_base, int c0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = sl_row + 16 * i;
+      const u32x4 t = *stg_at(stg, row, sl_pc);
+      if (m_base + row < p.M) *reinterpret_cast<u32x4*>(base + (size_t)(m_base + row) * ld + c0 + sl_pc * 8) = t;
+    }
+  };
   const int m_tile = seq / tiles_n;
   const int n0 = (seq - m_tile * tiles_n) * BN, m0 = m_tile * BM;
   const int mw = m0 + wm * WM, nw = n0 + wn * WN;
@@ -134,11 +173,12 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
     // [16 value | 16 gate] per 32 packed rows: fragment a holds value (registers q = 0, 1) and gate (q = 2, 3) of 16 outputs
     // in the same lane.  One v_permlane32_swap per register pair (q = 0 of the upper lanes <-> q = 1 of the lower lanes) leaves
     // a lane with 8 consecutive output columns: one 16-B store.
-    static_for<0, TN, 1>([&](auto AI) {
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+     static_for<0, TN, 1>([&](auto AI) {
       constexpr int a = decltype(AI)::value;
       const int npk = nw + a * 32;
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
+      {
         float o[8];
         f32x2 st = {0.0f, 1.0f};
         if (epi & IDF_EPI_LN_ROW) {
@@ -178,12 +218,26 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
         }
         const int m = mw + b * 32 + l31;
-        if (m < p.M) {
-          unsigned short* op = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + (npk >> 1) + 8 * hi;
+        unsigned short* const obase = reinterpret_cast<unsigned short*>(p.out);
+        if constexpr (STG) {
+          // a fragment leaves 32 B per row (the lane's 8 columns + its partner half's): two fragments fill the slot's 64-B rows
+          *stg_at(stg, l31, 2 * (a & 1) + hi) = pack8<DT>(v);
+          if constexpr ((a & 1) == 1) {
+            stg_store64(obase, p.ldo, mw + b * 32, (nw >> 1) + (a - 1) * 16);
+          } else if constexpr (a == TN - 1) {                 // odd fragment count: the last one goes out alone, 32 B per row
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int lane = l31 + 32 * hi, row = lane >> 1, pc = lane & 1;
+            const u32x4 t = *stg_at(stg, row, pc);
+            if (mw + b * 32 + row < p.M)
+              *reinterpret_cast<u32x4*>(obase + (size_t)(mw + b * 32 + row) * p.ldo + (nw >> 1) + a * 16 + pc * 8) = t;
+          }
+        } else if (m < p.M) {
+          unsigned short* op = obase + (size_t)m * p.ldo + (npk >> 1) + 8 * hi;
           *reinterpret_cast<u32x4*>(op) = pack8<DT>(v);
         }
       }
-    });
+     });
+    }
    }
   } else if (!GLU && (epi & IDF_EPI_GEGLU)) {
     if constexpr (!GLU && (TN & 1) == 0) {
@@ -226,7 +280,11 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           float v[16];
           swap16(o, v);
           const int m = mw + b * 32 + l31;
-          if (m < p.M) {
+          if constexpr (STG) {
+            *stg_at(stg, l31, 2 * hi) = pack8<DT>(v);
+            *stg_at(stg, l31, 2 * hi + 1) = pack8<DT>(v + 8);
+            stg_store64(reinterpret_cast<unsigned short*>(p.out), p.ldo, mw + b * 32, npk >> 1);
+          } else if (m < p.M) {
             unsigned short* op = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + (npk >> 1) + 16 * hi;
             *reinterpret_cast<u32x4*>(op) = pack8<DT>(v);
             *reinterpret_cast<u32x4*>(op + 8) = pack8<DT>(v + 8);
@@ -255,16 +313,16 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
         float v[16];
         swap16(acc[a][b], v);
         const int m = mw + b * 32 + l31;
-        if (m >= p.M) continue;
+        const int mc = min(m, p.M - 1);             // rows beyond M (last m-tile) compute on row M-1's side inputs, store nothing
         if (epi & IDF_EPI_LN_ROW) {                 // v = rstd_m * (acc - mu_m * c[n]); the beta term arrives as bias
           f32x2 st;
           if constexpr (LNS) st = f32x2{lnm[b], lnr[b]};
-          else st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)m);
+          else st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)mc);
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] = st[1] * fmaf(-st[0], cs[j >> 2][j & 3], v[j]);
         }
         if (epi & IDF_EPI_LN_COL) {                 // v = rstd_n * (acc - c[m] * mu_n) + d[m]: 16 token columns of row m
-          const float cm = p.ln_c[m], dm = p.ln_d[m];
+          const float cm = p.ln_c[mc], dm = p.ln_d[mc];
           const f32x4* st4 = reinterpret_cast<const f32x4*>(p.ln_stats + 2 * (size_t)n);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -278,7 +336,7 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           for (int j = 0; j < 16; ++j) v[j] += bs[j >> 2][j & 3];
         }
         if (epi & IDF_EPI_ROWBIAS) {
-          const unsigned short* rb = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n;
+          const unsigned short* rb = p.rowbias + (size_t)(mc / p.rows_per_batch) * p.ld_rowbias + n;
           float r[16];
           unpack8<DT>(*reinterpret_cast<const u32x4*>(rb), r);
           unpack8<DT>(*reinterpret_cast<const u32x4*>(rb + 8), r + 8);
@@ -294,23 +352,46 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           for (int j = 0; j < 16; ++j) v[j] = gelu_erf_f(v[j]);
         }
         if (epi & IDF_EPI_RES) {
-          const unsigned short* rr = p.res + (size_t)m * p.ldr + n;
           const float gm = (epi & IDF_EPI_GATE) ? gate : 1.0f;
           float r[16];
-          unpack8<DT>(*reinterpret_cast<const u32x4*>(rr), r);
-          unpack8<DT>(*reinterpret_cast<const u32x4*>(rr + 8), r + 8);
+          if constexpr (STG) {
+            // the fragment's 32 x 64 B of the residual: 16 rows x 64 contiguous bytes per load instruction, then each lane
+            // picks its own row's 32 B out of the slot
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int row = sl_row + 16 * i;
+              const int mr = min(mw + b * 32 + row, p.M - 1);
+              *stg_at(stg, row, sl_pc) = *reinterpret_cast<const u32x4*>(p.res + (size_t)mr * p.ldr + nw + a * 32 + sl_pc * 8);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unpack8<DT>(*stg_at(stg, l31, 2 * hi), r);
+            unpack8<DT>(*stg_at(stg, l31, 2 * hi + 1), r + 8);
+          } else {
+            const unsigned short* rr = p.res + (size_t)mc * p.ldr + n;
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(rr), r);
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(rr + 8), r + 8);
+          }
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] = fmaf(gm, v[j], r[j]);
         }
         if (epi & IDF_EPI_OUT_F32) {
-          float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+          if (m < p.M) {
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + 4 * j) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + 4 * j) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+          }
         } else {
-          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + n;
           const u32x4 q0 = pack8<DT>(v), q1 = pack8<DT>(v + 8);
-          *reinterpret_cast<u32x4*>(o) = q0;
-          *reinterpret_cast<u32x4*>(o + 8) = q1;
+          if constexpr (STG) {
+            asm volatile("" ::: "memory");            // the residual reads of the slot above are done before it is rewritten
+            *stg_at(stg, l31, 2 * hi) = q0;
+            *stg_at(stg, l31, 2 * hi + 1) = q1;
+            stg_store64(reinterpret_cast<unsigned short*>(p.out), p.ldo, mw + b * 32, nw + a * 32);
+          } else if (m < p.M) {
+            unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.ldo + n;
+            *reinterpret_cast<u32x4*>(o) = q0;
+            *reinterpret_cast<u32x4*>(o + 8) = q1;
+          }
           if constexpr (STATS) {
             float r[16];
             unpack8<DT>(q0, r);
@@ -668,6 +749,8 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
   TR_DECL
   const int epi = p.epi;
   const float gate = (epi & IDF_EPI_GATE) ? p.gate[0] : 0.0f;
+  // wave-private 2-KB slot behind the ring: epilogue staging (big_epilogue) / the LNS statistics of a transposed tile
+  char* const stg = reinterpret_cast<char*>(smem + NSTG * STAGE) + wave * 2048;
 
   // One output tile: accumulators cleared, the K loop, the epilogue.  SWAPT = the transposed-V tiles of the fused q | k | v
   // projection.  The accumulators are LOCAL to a tile kind: with one accumulator block shared by the plain and the swapped
@@ -758,7 +841,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
       if constexpr (LNS) {
         // the statistics this wave summed in the K loop, parked in its own LDS slice (behind the ring) so that the
         // transposed epilogue can read the pair of ANY of the wave's 64 rows: [row][2], row = b*32 + l31
-        float* stw = reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * (2 * WM);
+        float* stw = reinterpret_cast<float*>(stg);        // 2 * WM floats of the wave's 2-KB slot
         if (hi == 0) {
 #pragma unroll
           for (int b = 0; b < TM; ++b) *reinterpret_cast<f32x2*>(stw + 2 * (b * 32 + l31)) = f32x2{lnm[b], lnr[b]};
@@ -770,7 +853,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
         big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, p.ln_stats, 0);
       }
     } else {
-      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, lnm, lnr);
+      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, stg, lnm, lnr);
     }
     TR(4)
     // store instructions this wave just issued, at least (see the first K-tile's wait above)
@@ -840,7 +923,7 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
     if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT, false, GLU>(p, s, 1);
   }
   void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS, GLU>;
-  constexpr int smem = NSTG * (BM + BN) * BKT * 2 + ((VT && LNS) ? NWAVES * 2 * WM * 4 : 0);
+  constexpr int smem = NSTG * (BM + BN) * BKT * 2 + NWAVES * 2048;      // ring + one 2-KB slot per wave (160 KB at BN = 320)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -960,8 +1043,10 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
   }
   ++idf_stat_big_launches;
   // output-row statistics from the epilogue registers: unsplit dense 16-bit-output GEMMs whose epilogue is the plain one
+  // ... and the workspace holds one (mean, M2) slot per row and wave column half: [M][2 * N / bn][2] floats
   const bool stats = parts_out && p.stat_parts && !conv && !geglu && !vt && !self_ln && splitk == 1 && bn != 128 &&
-                     !(p.epi & IDF_EPI_OUT_F32) && (((uintptr_t)p.stat_parts) & 7u) == 0;
+                     !(p.epi & IDF_EPI_OUT_F32) && (((uintptr_t)p.stat_parts) & 7u) == 0 &&
+                     (size_t)p.M * (size_t)(2 * (p.N / bn)) * 2 * sizeof(float) <= p.ws_bytes;
   CoreParams ps = p;
   if (stats) { ps.parts = 2 * (p.N / bn); *parts_out = ps.parts; }
   CoreParams pq = p;                                      // split launches: uniform split-K (full 0) or hybrid

@@ -526,7 +526,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // profiles/r01_diag_B18_gemm_ring_vs_dma.log.
 int g_big_mode = -2;
 inline int gemm_big_mode() {
-  if (g_big_mode == -2) { const char* e = getenv("IDF_GEMM_BIG"); g_big_mode = e ? atoi(e) : IDF_GEMM_BIG_DEFAULT; }
+  if (g_big_mode == -2) {
+    const char* e = getenv("IDF_GEMM_BIG");
+    const int v = e ? atoi(e) : IDF_GEMM_BIG_DEFAULT;
+    g_big_mode = (v < 0 || v > 3) ? IDF_GEMM_BIG_DEFAULT : v;            // out of range = default (as idf_set_tuning rejects it)
+  }
   return g_big_mode;
 }
 
@@ -717,6 +721,10 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
     const int Nv = a->N - a->vt_col0;
     if (a->vt_col0 <= 0 || Nv <= 0 || batch != 1 || a->ld_vt < a->M || (a->ld_vt % 8) || !aligned16(a->vt_out)) return IDF_E_ARG;
     if (a->epi & ~(IDF_EPI_BIAS | IDF_EPI_LN_ROW)) return IDF_E_ARG;
+    // LN_ROW is required: the two-GEMM form carries the transposed columns' bias / beta term as the LN_COL row vector, and a
+    // result must not depend on which form the tuning mode and the CU count select (a BIAS-only call used to fail
+    // in the fallback AFTER the q | k GEMM had been launched)
+    if (!(a->epi & IDF_EPI_LN_ROW)) return IDF_E_ARG;
     if (a->out_stats) return IDF_E_ARG;
     const bool self_ln = (a->epi & IDF_EPI_LN_ROW) && !a->ln_stats;
     if (self_ln && !a->ln_stats_out) return IDF_E_ARG;        // the fallback's second GEMM needs them somewhere
@@ -740,8 +748,6 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
       p2.epi |= IDF_EPI_LN_COL;
       p2.ln_stats = self_ln ? a->ln_stats_out : a->ln_stats; p2.stride_ln_stats = 0;
       p2.ln_c = a->ln_c + a->vt_col0; p2.ln_d = a->bias + a->vt_col0;
-    } else if (a->epi & IDF_EPI_BIAS) {
-      return IDF_E_UNSUPPORTED;                                 // a per-row bias of the transposed product: no caller needs it
     }
     if (a->dtype == IDF_BF16) return launch<IDF_BF16, false>(p2, 1, s);
     if (a->dtype == IDF_F16) return launch<IDF_F16, false>(p2, 1, s);
@@ -751,7 +757,8 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   // (when it takes the launch, unsplit) and a 16-B-per-row finalize pass merges them; otherwise the statistics pass re-reads
   // the output as before
   int parts = 0;
-  if (a->out_stats && batch == 1 && p.ws && p.ws_bytes >= (size_t)a->M * 32 * sizeof(float)) p.stat_parts = p.ws;
+  // (whether the workspace holds the [M][parts][2] partials is checked where `parts` is chosen: idf_launch_big)
+  if (a->out_stats && batch == 1 && p.ws) p.stat_parts = p.ws;
   if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p, batch, s, &parts);
   else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p, batch, s, &parts);
   if (rc == 0 && a->out_stats) {

@@ -1,0 +1,283 @@
+// mlp_fused.hip -- the GEGLU feed-forward of a C = 320 transformer block as ONE kernel (gfx950):
+//     out = x + [gate *] ( W2 . ( value * gelu(gate) ) + b2 ),   (value | gate) = LN(x) . W1^T + b1
+// (attention.py:36-63 GEGLU / FeedForward, call sites :309 `x + tanh(alpha_dense) * ff(norm2(x))` and :337 `ff(norm3(x)) + x`).
+//
+// Why.  As two GEMMs the 4C-wide activated intermediate H is written to HBM and read back -- 2 x 1.34 GB per MLP at 128 rows
+// of 64 x 64 latents -- the first GEMM (K = 320: five K-tiles per output tile) spends 40 % of its time in an epilogue that
+// cannot overlap its own K loop (GELU on the VALU, then a store burst at the CU's ~12 B/clk store rate: rounds 3-4 traces,
+// profiles/r04_big_stage_epilogue.log), and the second one is HBM-bound on reading H.  Here H never leaves the CU:
+//
+//   * one persistent 512-thread workgroup (8 wave64, 2 per SIMD) per CU walks 128-row tiles; wave (wm, wn) owns rows
+//     32 wm .. + 31 and the output columns 160 wn .. + 159;
+//   * the tile's activation rows live in REGISTERS for the whole tile: 20 MFMA B-operand fragments (80 VGPRs) per lane, read
+//     once from global memory -- X never touches LDS;
+//   * the weights stream through a 2-slot LDS ring by LDS-DMA in 40 chunks of 32 intermediate columns: W1 rows
+//     [64 j, 64 j + 64) (period-32 packing: [16 value | 16 gate] per 32 rows), the matching 32 columns of W2, and the 64 + 64
+//     LayerNorm-fold constants (c, d) of those rows -- 61 KB per chunk, the same 31 B/clk per CU at full MFMA rate as the
+//     256 x 320 GEMM tile;
+//   * per chunk, wave (wm, wn) computes the 32 x 32 pre-activation fragment of W1 rows 64 j + 32 wn .. (20 MFMAs, K = 320, B
+//     operand from registers), applies LayerNorm fold + bias + GEGLU in registers and packs the 16 activated columns of its
+//     32 rows to the 16-bit type -- which IS an MFMA B-operand fragment of the second GEMM (lane = row, 8 consecutive
+//     registers = 8 k values; the k order inside a 16-group is a fixed permutation that W2's packed image carries too).  The
+//     two waves of a row group exchange their fragments through 1 KB of LDS each, and both run the second GEMM's two k-steps
+//     for their own 160 output columns (10 MFMAs, accumulators 80 VGPRs, live across the 40 chunks);
+//   * epilogue once per tile: + b2, gate, + residual, 16-bit store (80 KB per 314 MFLOP instead of 720 KB of H and output).
+//
+// Numerics: as the two-GEMM path -- fp32 accumulation, H rounded to the 16-bit type before the second product -- up to the
+// summation order of the second GEMM.  LDS: 2 x 61 KB ring + 8 KB exchange + 16 KB epilogue staging = 146 KB.
+// Roofline: MFMA-bound, 2 * M * (2560 * 320 + 320 * 1280) flops; HBM: 2 B in + 2 B out per element of x (+ residual read).
+#include "gemm_core.h"
+
+using namespace idfcore;
+
+namespace {
+
+constexpr int MLP_C = 320, MLP_H = 1280, MLP_CH = 32, MLP_NCH = MLP_H / MLP_CH;     // 40 chunks of 32 intermediate columns
+constexpr int MLP_BM = 128;
+constexpr int W1_BYTES = 5 * 64 * 128;          // 5 K-tiles x [64 rows][64 k]: 128-B rows, 16-B slot ^= (row >> 1) & 7
+constexpr int W2_BYTES = 320 * 64;              // [320 rows][32 k]: 64-B rows, 16-B slot ^= (row >> 2) & 3
+constexpr int CD_BYTES = 1024;                  // c[64] | d[64] fp32 (+ 512 B the DMA instruction fills with a copy)
+constexpr int SLOT_BYTES = W1_BYTES + W2_BYTES + CD_BYTES;
+constexpr int XCH_OFF = 2 * SLOT_BYTES, STG_OFF = XCH_OFF + 8 * 1024, MLP_SMEM = STG_OFF + 8 * 2048;
+
+struct MlpParams {
+  const unsigned short* x; int ldx;             // [M][320] 16-bit: the LayerNorm input AND the residual
+  const float* ln_stats;                        // [M][2] (mu, rstd)
+  const unsigned short* w1; int ldw1;           // [2560][320] gamma-folded, rows packed [16 value | 16 gate] per 32
+  const float* cd;                              // [40][128]: per chunk c[64] | d[64] of its 64 packed rows
+  const unsigned short* w2p; int ldw2;          // [320][1280], k permuted inside every 16-group (mlp_w2_perm)
+  const float* b2; const float* gate;           // [320]; device scalar or nullptr
+  unsigned short* out; int ldo;
+  int M;
+};
+
+__device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(size_t)p; }
+// LDS-DMA as inline assembly (see gemm_big.hip): lds = LDS byte address of lane 0's 16-B slot, through M0
+__device__ __forceinline__ void mlp_dma16(const void* sbase /* wave-uniform */, unsigned voff_bytes, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_bytes), "s"(sbase) : "memory");
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const int tiles) {
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int G = gridDim.x;
+
+  // ---- LDS-DMA roles (per-lane source offsets are the same for every chunk; the chunk moves the wave-uniform base)
+  // W1: piece (t, wave) = rows 8 wave .. + 7 of K-tile t: lane -> row 8 wave + lane / 8, slot lane % 8
+  unsigned w1_voff, w2_voff[3];
+  {
+    const int row = 8 * wave + (lane >> 3);
+    const int src = (lane & 7) ^ ((row >> 1) & 7);
+    w1_voff = (unsigned)(row * p.ldw1 + src * 8) * 2u;
+  }
+  // W2: piece i = rows 16 i .. + 15: lane -> row 16 i + lane / 4, slot lane % 4; pieces wave, wave + 8, (wave + 16 < 20)
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int row = 16 * (wave + 8 * t) + (lane >> 2);
+    const int src = (lane & 3) ^ ((row >> 2) & 3);
+    w2_voff[t] = (unsigned)(row * p.ldw2 + src * 8) * 2u;
+  }
+  auto issue_chunk = [&](int j, int slot) {
+    char* const base = smem + slot * SLOT_BYTES;
+    const unsigned short* w1j = p.w1 + (size_t)j * 64 * p.ldw1;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) mlp_dma16(w1j + t * 64, w1_voff, lds_u32(base + t * 8192 + wave * 1024));
+    const unsigned short* w2j = p.w2p + j * 32;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (wave + 8 * t < 20) mlp_dma16(w2j, w2_voff[t], lds_u32(base + W1_BYTES + (wave + 8 * t) * 1024));
+    if (wave == 7) mlp_dma16(p.cd + (size_t)j * 128, (unsigned)((lane & 31) * 16), lds_u32(base + W1_BYTES + W2_BYTES));
+  };
+
+  // ---- fragment addressing
+  const int sw1 = (l31 >> 1) & 7, sw2 = (l31 >> 2) & 3;
+  const int w1_row = (32 * wn + l31) * 128;                    // byte offset of the lane's W1 row inside a K-tile image
+  const int w2_row = W1_BYTES + (160 * wn + l31) * 64;         // ... of its W2 row for output fragment 0 (+ 2048 per fragment)
+  char* const xch_mine = smem + XCH_OFF + wave * 1024 + lane * 16;
+  char* const xch_peer = smem + XCH_OFF + (wave ^ 1) * 1024 + lane * 16;
+  char* const stg = smem + STG_OFF + wave * 2048;
+
+  int tile = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= tiles) return;
+  const float gate = p.gate ? p.gate[0] : 1.0f;
+
+  issue_chunk(0, 0);
+  int g = 0;                                                   // chunks consumed so far (ring slot = g & 1)
+  for (; tile < tiles; tile += G) {
+    const int m = tile * MLP_BM + wm * 32 + l31;               // the lane's row
+    // activation rows: 20 B-operand fragments, elements 16 ks + 8 hi .. + 7 of row m
+    u32x4 xf[20];
+    {
+      const unsigned short* xr = p.x + (size_t)m * p.ldx + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 20; ++ks) xf[ks] = *reinterpret_cast<const u32x4*>(xr + 16 * ks);
+    }
+    const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)m);
+    const float nmu = -st[0], rstd = st[1];
+    f32x16 acc2[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[a][r] = 0.0f;
+
+    for (int j = 0; j < MLP_NCH; ++j, ++g) {
+      // chunk g has landed (this wave's pieces; the barrier publishes everyone's) and every wave is done with the other slot
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const bool last = (j == MLP_NCH - 1) && (tile + G >= tiles);
+      if (!last) issue_chunk(j + 1 == MLP_NCH ? 0 : j + 1, (g + 1) & 1);
+      const char* const sl = smem + (g & 1) * SLOT_BYTES;
+
+      // ---- GEMM 1: the 32 x 32 pre-activation fragment of packed W1 rows 64 j + 32 wn ..: 20 k-steps, B operand = xf
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+      {
+        const char* wb = sl + w1_row;
+        u32x4 wf[2];
+        wf[0] = *reinterpret_cast<const u32x4*>(wb + ((hi ^ sw1) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 20; ++ks) {
+          if (ks + 1 < 20) {
+            const int kt = (ks + 1) >> 2, c = 2 * ((ks + 1) & 3) + hi;
+            wf[(ks + 1) & 1] = *reinterpret_cast<const u32x4*>(wb + kt * 8192 + ((c ^ sw1) << 4));
+          }
+          acc1 = Elem<DT>::mfma32(wf[ks & 1], xf[ks], acc1);
+        }
+      }
+      // ---- LayerNorm fold + bias + GEGLU in registers: acc1[4 q + e] = pre[packed row 8 q + 4 hi + e][row l31]; rows 0..15 of
+      // the fragment are the values, 16..31 the gates of intermediate columns 0..15: the lane ends up with columns
+      // {4 hi + e, 8 + 4 hi + e}, which (in this order) are the 8 k values of its half of the second GEMM's 16-wide k-step
+      u32x4 hmine;
+      {
+        const float* cdp = reinterpret_cast<const float*>(sl + W1_BYTES + W2_BYTES) + 32 * wn + 4 * hi;
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(cdp + 8 * q), cg = *reinterpret_cast<const f32x4*>(cdp + 16 + 8 * q);
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(cdp + 64 + 8 * q), dg = *reinterpret_cast<const f32x4*>(cdp + 80 + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float val = fmaf(rstd, fmaf(nmu, cv[e], acc1[4 * q + e]), dv[e]);
+            const float gat = fmaf(rstd, fmaf(nmu, cg[e], acc1[4 * (q + 2) + e]), dg[e]);
+            o[4 * q + e] = val * gelu_erf_f(gat);
+          }
+        }
+        hmine = pack8<DT>(o);
+      }
+      // ---- exchange with the other wave of this row group (it holds the other 16 intermediate columns of the chunk)
+      *reinterpret_cast<u32x4*>(xch_mine) = hmine;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const u32x4 hpeer = *reinterpret_cast<const u32x4*>(xch_peer);
+      // ---- GEMM 2: two k-steps (the fragment of wn = 0, then of wn = 1) x 5 output fragments
+      {
+        const char* wb = sl + w2_row;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const u32x4 hf = (kk == wn) ? hmine : hpeer;
+          u32x4 w2f[5];
+#pragma unroll
+          for (int a = 0; a < 5; ++a) w2f[a] = *reinterpret_cast<const u32x4*>(wb + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
+#pragma unroll
+          for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[a], hf, acc2[a]);
+        }
+      }
+    }
+
+    // ---- tile epilogue: + b2, gate, + residual; 32 x 32 fragments through the wave's 2-KB slot so that a store instruction
+    // covers 16 rows x 64 contiguous bytes (gemm_big.hip "coalesced epilogue accesses"; same slot image)
+    const int sl_row = lane >> 2, sl_pc = lane & 3;
+    auto stg_f = [](int row) { return ((((row >> 2) ^ (row >> 3)) & 1) << 1) | (((row >> 1) ^ (row >> 3) ^ (row >> 4)) & 1); };
+    auto stg_at = [&](int row, int pc) { return reinterpret_cast<u32x4*>(stg + row * 64 + ((pc ^ stg_f(row)) << 4)); };
+    const int m_base = tile * MLP_BM + wm * 32;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const int n = 160 * wn + 32 * a;
+      // residual rows, coalesced
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = sl_row + 16 * i;
+        *stg_at(row, sl_pc) = *reinterpret_cast<const u32x4*>(p.x + (size_t)(m_base + row) * p.ldx + n + sl_pc * 8);
+      }
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc2[a][e]), __float_as_uint(acc2[a][8 + e]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc2[a][4 + e]), __float_as_uint(acc2[a][12 + e]), false, false);
+        v[e] = __uint_as_float(s02[0]); v[4 + e] = __uint_as_float(s02[1]);
+        v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
+      }
+      const float* bp = p.b2 + n + 16 * hi;
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bp + 4 * jq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * jq + e] += bq[e];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float r[16];
+      unpack8<DT>(*stg_at(l31, 2 * hi), r);
+      unpack8<DT>(*stg_at(l31, 2 * hi + 1), r + 8);
+#pragma unroll
+      for (int jq = 0; jq < 16; ++jq) v[jq] = fmaf(gate, v[jq], r[jq]);
+      asm volatile("" ::: "memory");
+      *stg_at(l31, 2 * hi) = pack8<DT>(v);
+      *stg_at(l31, 2 * hi + 1) = pack8<DT>(v + 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = sl_row + 16 * i;
+        *reinterpret_cast<u32x4*>(p.out + (size_t)(m_base + row) * p.ldo + n + sl_pc * 8) = *stg_at(row, sl_pc);
+      }
+    }
+  }
+}
+
+template <int DT>
+int launch_mlp320(const MlpParams& p, hipStream_t s) {
+  void (*kern)(const MlpParams, const int) = mlp320_kernel<DT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int tiles = p.M / MLP_BM;
+  const int grid = tiles < cus ? tiles : cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), MLP_SMEM, s, p, tiles);
+  return idf_launch_status();
+}
+
+}  // namespace
+
+extern "C" int idf_mlp_geglu(const idf_mlp_args* a, void* stream) {
+  if (!a) return IDF_E_ARG;
+  if (!a->x || !a->ln_stats || !a->w1 || !a->cd || !a->w2p || !a->b2 || !a->out) return IDF_E_ARG;
+  if (a->M <= 0 || a->C <= 0) return IDF_E_ARG;
+  if (a->dtype != IDF_BF16 && a->dtype != IDF_F16) return IDF_E_ARG;
+  if (a->C != MLP_C || (a->M % MLP_BM) != 0) return IDF_E_UNSUPPORTED;
+  if (a->ldx < MLP_C || a->ldo < MLP_C || a->ldw1 < MLP_C || a->ldw2 < MLP_H) return IDF_E_ARG;
+  if ((a->ldx % 8) || (a->ldo % 8) || (a->ldw1 % 8) || (a->ldw2 % 8)) return IDF_E_ALIGN;
+  if (!aligned16(a->x) || !aligned16(a->out) || !aligned16(a->w1) || !aligned16(a->w2p) || !aligned16(a->cd) || !aligned16(a->b2) ||
+      (((uintptr_t)a->ln_stats) & 7u))
+    return IDF_E_ALIGN;
+  // 32-bit per-lane DMA offsets
+  if ((long long)64 * a->ldw1 * 2 >= (1ll << 31) || (long long)320 * a->ldw2 * 2 >= (1ll << 31)) return IDF_E_UNSUPPORTED;
+  MlpParams p;
+  p.x = static_cast<const unsigned short*>(a->x); p.ldx = a->ldx; p.ln_stats = a->ln_stats;
+  p.w1 = static_cast<const unsigned short*>(a->w1); p.ldw1 = a->ldw1; p.cd = a->cd;
+  p.w2p = static_cast<const unsigned short*>(a->w2p); p.ldw2 = a->ldw2; p.b2 = a->b2; p.gate = a->gate;
+  p.out = static_cast<unsigned short*>(a->out); p.ldo = a->ldo; p.M = a->M;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return a->dtype == IDF_BF16 ? launch_mlp320<IDF_BF16>(p, s) : launch_mlp320<IDF_F16>(p, s);
+}

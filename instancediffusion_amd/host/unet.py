@@ -75,9 +75,9 @@ class UNetModel(nn.Module):
                  inpaint_mode=False, grounding_downsampler=None, grounding_tokenizer=None, sd_v1_5=False,
                  efficient_attention=False):
         super().__init__()
+        # openaimodel.py:349 accepts all three names; BasicTransformerBlock builds a GatedSelfAttentionDense whatever the
+        # value (attention.py:325), so all three name the same network here too
         assert fuser_type in ["gatedSA", "gatedSA2", "gatedCA"]
-        if fuser_type != "gatedSA":
-            raise NotImplementedError("reference BasicTransformerBlock only ever builds GatedSelfAttentionDense")
         assert dims == 2 and conv_resample and not use_scale_shift_norm and transformer_depth == 1
         self.image_size = image_size
         self.in_channels = in_channels

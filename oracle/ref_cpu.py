@@ -562,9 +562,19 @@ def _step_common(model: OracleModel, alphas, i):
             model.restore_first_conv_from_SD()
 
 
+def q_sample(x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """LatentDiffusion.q_sample, ldm.py:17-20 (buffers registered in float32, ddpm.py:33-36)."""
+    ac = torch.tensor(alphas_cumprod(), dtype=torch.float32)
+    shape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+    return ac.sqrt()[t].reshape(shape) * x_start + (1.0 - ac).sqrt()[t].reshape(shape) * noise
+
+
 def plms_sample(model: OracleModel, S: int, inp: dict, uc, guidance_scale: float,
-                alpha_type: Optional[Sequence[float]] = None, trace: Optional[list] = None) -> torch.Tensor:
-    """PLMSSampler.sample / plms_sampling, plms.py:66-113."""
+                alpha_type: Optional[Sequence[float]] = None, trace: Optional[list] = None,
+                mask: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
+                noises: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PLMSSampler.sample / plms_sampling, plms.py:66-113.  ``mask`` / ``x0``: the inpainting blend of plms.py:99-104 in
+    front of every step; ``noises[i]`` is the noise q_sample draws at step i (the reference draws it from the global RNG)."""
     steps, a, a_prev = _schedule(S)
     time_range = np.flip(steps)
     total = steps.shape[0]
@@ -577,6 +587,10 @@ def plms_sample(model: OracleModel, S: int, inp: dict, uc, guidance_scale: float
         index = total - i - 1
         ts = torch.full((b,), int(step), dtype=torch.long)
         ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        if mask is not None:                                   # plms.py:99-104
+            assert x0 is not None and noises is not None
+            img = q_sample(x0, ts, noises[i]) * mask + (1.0 - mask) * img
+            inp["x"] = img
         img, e_t = _p_sample_plms(model, inp, ts, index, a, a_prev, uc, guidance_scale, old_eps, ts_next)
         inp["x"] = img
         old_eps.append(e_t)

@@ -79,6 +79,20 @@ def test_samplers_match_reference(tag):
         _check(out, gold["mis"], TRAJ_TOL, "MIS trajectory")
 
 
+def test_plms_mask_blend_matches_reference():
+    """PLMSSampler.sample(mask=, x0=): the inpainting blend of plms.py:99-104, pinned to the unmodified reference
+    (golden ``tiny_box_plms_mask``: its q_sample noise draws are stored with the golden and replayed here)."""
+    gold, meta, cfg, sd, inp = _setup("tiny_box_plms_mask")
+    with torch.no_grad():
+        model = ref_cpu.OracleModel(sd, cfg, synth.synth_first_conv_sd())
+        i0 = dict(x=inp["x"].clone(), timesteps=None, context=inp["context"], grounding_input=ref_cpu.prepare_grounding(inp["gb"]))
+        out = ref_cpu.plms_sample(model, meta["S"], i0, inp["uc"], 7.5, alpha_type=meta["alpha_type"], mask=gold["mask"],
+                                  x0=gold["x0"], noises=gold["noises"])
+    _check(out, gold["plms_masked"], TRAJ_TOL, "PLMS trajectory with the mask / x0 blend")
+    # the blend matters: without it the trajectory ends somewhere else
+    assert cases.rel_rms(out, cases.load_golden("tiny_box")["plms"]) > 0.1
+
+
 @heavy
 def test_full_model_headline_trajectory_matches_reference():
     """The headline trajectory on the headline model (golden ``full_box_s50``: the unmodified reference PLMSSamplerInst, full

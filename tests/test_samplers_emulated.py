@@ -54,6 +54,24 @@ def test_plms_matches_reference(tag):
     assert cases.rel_rms(out, gold["plms"]) < 5e-3
 
 
+def _replay_q_sample(diffusion, noises, device):
+    """q_sample with the golden's recorded noise draws instead of the global RNG (one draw per PLMS step, in order)."""
+    real, it = diffusion.q_sample, iter(noises)
+    diffusion.q_sample = lambda x_start, t, noise=None: real(x_start, t, noise=next(it).to(device))
+
+
+def test_plms_mask_blend_matches_reference():
+    """PLMSSampler.sample(mask=, x0=) (plms.py:99-104) against the unmodified reference's trajectory."""
+    gold, meta, inp, model, gi, diffusion = setup("tiny_box_plms_mask")
+    _replay_q_sample(diffusion, gold["noises"], "cpu")
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
+                          set_alpha_scale=set_alpha_scale)
+    i0 = dict(x=inp["x"].clone(), timesteps=None, context=inp["context"], grounding_input=gi.prepare(inp["gb"]))
+    out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=i0, uc=inp["uc"], guidance_scale=7.5,
+                         mask=gold["mask"], x0=gold["x0"])
+    assert cases.rel_rms(out, gold["plms_masked"]) < 5e-3
+
+
 @pytest.mark.parametrize("tag", ["tiny_box", "mid_box"])
 def test_mis_matches_reference(tag):
     gold, meta, inp, model, gi, diffusion = setup(tag)
@@ -102,12 +120,24 @@ def _single_process_run(sampler, meta, inp, gi):
         torch.set_num_threads(n)
 
 
-def _dist_worker(rank, world, port, q, sharding="auto"):
+def _tile_batch(inp, rep):
+    """The case's inputs with the batch tiled `rep` times: image b of the result is image b % batch of the case."""
+    if rep == 1:
+        return inp
+
+    def t(v):
+        return v.repeat(rep, *([1] * (v.dim() - 1))) if torch.is_tensor(v) and v.dim() > 0 else v
+    return dict(x=t(inp["x"]), context=t(inp["context"]), uc=t(inp["uc"]), t=t(inp["t"]),
+                gb={k: t(v) for k, v in inp["gb"].items()}, inst_ctx=[t(c) for c in inp["inst_ctx"]])
+
+
+def _dist_worker(rank, world, port, q, sharding="auto", rep=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    torch.set_num_threads(WORKER_THREADS)
+    torch.set_num_threads(WORKER_THREADS if rep == 1 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
+    inp = _tile_batch(inp, rep)
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
                               set_alpha_scale=set_alpha_scale, mis=meta["mis"], unit_sharding=sharding)
     out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
@@ -187,6 +217,44 @@ def test_mis_sharded_world3_more_ranks_than_images_gloo():
     print(f"[world 3, instance] attention rows: single process {single}, per rank {rows}")
     assert all(0 < n < single for n in rows), (single, rows)
     assert max(rows) <= 0.60 * single and sum(rows) <= 1.30 * single, (single, rows)
+
+
+def test_mis_sharded_world8_one_image_per_rank_gloo():
+    """The headline deployment shape in small: 8 ranks, 8 images (one per rank), `instance` ownership -- the N+1 trajectories
+    of every image run on N+1 different ranks, the merge all-gathers the unit latents each rank owns, phase 2 runs one image per
+    rank and the finished images are all-gathered.  Every rank must return the single-process result bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, rep = 8, 4
+    port = 29500 + (os.getpid() % 500) + 21
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q, "instance", rep)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=1200) for _ in procs], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(o), n) for r, o, n in res]
+    for p in procs:
+        p.join(timeout=60)
+    gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
+    assert meta["batch"] * rep == world
+    inp = _tile_batch(inp, rep)
+    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
+                              set_alpha_scale=set_alpha_scale, mis=meta["mis"])
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        one = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
+                             guidance_scale=7.5)
+    finally:
+        torch.set_num_threads(n)
+    for b in range(world):                                  # every image is a copy of one of the golden's two
+        assert cases.rel_rms(one[b:b + 1], gold["mis"][b % meta["batch"]][None]) < 5e-3, b
+    for rank, out, _ in res:
+        assert torch.equal(one, out), f"rank {rank} of world 8 must be bit-identical to one process"
+    single = sampler.engine.ops.rows["attention"]
+    rows = [n for _, _, n in res]
+    print(f"[world 8, instance, one image per rank] attention rows: single process {single}, per rank {rows}")
+    assert max(rows) <= 0.30 * single and sum(rows) <= 1.6 * single, (single, rows)
 
 
 def test_shared_unconditional_row_is_built_once_and_changes_nothing(monkeypatch):

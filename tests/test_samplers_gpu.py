@@ -83,6 +83,27 @@ def _run_mis(tag, dtype, second_call=False):
         assert torch.isfinite(out2).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_plms_mask_blend_matches_reference(dtype):
+    """PLMSSampler.sample(mask=, x0=): the inpainting blend of plms.py:99-104 (``img = q_sample(x0, ts) * mask +
+    (1 - mask) * img`` in front of every step) on the HIP engine against the unmodified reference's trajectory
+    (golden ``tiny_box_plms_mask``; the reference's q_sample noise draws are stored with it and replayed)."""
+    from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.samplers import PLMSSampler
+    from tests import cases
+    gold, meta, inp, model, gi, diffusion = _setup("tiny_box_plms_mask", dtype)
+    real, it = diffusion.q_sample, iter(gold["noises"])
+    diffusion.q_sample = lambda x_start, t, noise=None: real(x_start, t, noise=next(it).cuda())
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
+                          set_alpha_scale=set_alpha_scale)
+    i0 = dict(x=inp["x"].cuda(), timesteps=None, context=inp["context"].cuda(), grounding_input=gi.prepare(_cuda(inp["gb"])))
+    out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=i0, uc=inp["uc"].cuda(), guidance_scale=7.5,
+                         mask=gold["mask"].cuda(), x0=gold["x0"].cuda())
+    err = cases.rel_rms(out.cpu(), gold["plms_masked"])
+    print(f"[parity] tiny_box PLMS S={meta['S']} with mask / x0 blend {dtype}: latent rel-rms {err:.3e} (tol {TRAJ_TOL[dtype]:.0e})")
+    assert torch.isfinite(out).all() and err < TRAJ_TOL[dtype]
+
+
 @pytest.mark.parametrize("tag", ["tiny_box", "mid_box"])
 def test_plms_and_mis_match_reference(tag):
     _run_plms(tag, torch.bfloat16)

@@ -66,12 +66,24 @@ int main(int argc, char** argv) {
       {"conv 32^2 640 bias", 0, 640, 0, IDF_EPI_BIAS, true, 128, 32, 640},
       {"conv 16^2 1280 bias", 0, 1280, 0, IDF_EPI_BIAS, true, 128, 16, 1280},
       {"conv 64^2 640->320 +res", 0, 320, 0, IDF_EPI_BIAS | IDF_EPI_RES, true, 128, 64, 640},
+      // correctness corners of the staged epilogue: a last m-tile with 156 valid rows, the 256-wide tiles (plain, period-64
+      // and period-32 GEGLU), a ragged conv
+      {"proj ragged M bias+res", 262044, 320, 320, BR, false, 0, 0, 0},
+      {"geglu ragged M", 131000, 2560, 320, GLU, false, 0, 0, 0},
+      {"256-wide bias+res", 65536, 1024, 1024, BR, false, 0, 0, 0},
+      {"geglu period-64 256-wide", 131072, 5120, 640, IDF_EPI_BIAS | IDF_EPI_GEGLU, false, 0, 0, 0},
+      {"geglu period-32 256-wide", 65536, 2048, 640, GLU, false, 0, 0, 0},
+      {"conv 24^2 640 ragged +res", 0, 640, 0, IDF_EPI_BIAS | IDF_EPI_RES, true, 33, 24, 640},
   };
+#ifdef BIG_SCHED_SHORT
+  const Cfg cfgs[] = {{"base", 0, 0, 0}, {"epivm", 0, 0, 1}};
+#else
   const Cfg cfgs[] = {
       {"base", 0, 0, 0},      {"walk", 1, 0, 0},          {"epivm", 0, 0, 1},          {"walk+epivm", 1, 0, 1},
       {"deph2", 0, 2, 0},     {"deph4", 0, 4, 0},         {"deph8", 0, 8, 0},          {"walk+epivm+deph2", 1, 2, 1},
       {"walk+epivm+deph4", 1, 4, 1}, {"walk+epivm+deph8", 1, 8, 1},
   };
+#endif
   constexpr int NC = sizeof(cfgs) / sizeof(cfgs[0]);
   BigSched& sc = big_sched();
   sc.dephase_min_rounds = 1;

@@ -51,6 +51,11 @@ class AttnArgs(C.Structure):
                 ("qbits", vp), ("strideQb", ll), ("kbits0", vp), ("strideKb0", ll), ("kbits1", vp), ("strideKb1", ll)]
 
 
+class MlpArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", ci), ("ln_stats", vp), ("w1", vp), ("ldw1", ci), ("cd", vp), ("w2p", vp), ("ldw2", ci),
+                ("b2", vp), ("gate", vp), ("out", vp), ("ldo", ci), ("M", ci), ("C", ci), ("dtype", ci)]
+
+
 # every symbol include/idf.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "idf_abi_version": (ci, []),
@@ -59,6 +64,7 @@ SYMBOLS = {
     "idf_get_stat": (ll, [ci]),
     "idf_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "idf_conv3x3": (ci, [C.POINTER(ConvArgs), vp]),
+    "idf_mlp_geglu": (ci, [C.POINTER(MlpArgs), vp]),
     "idf_conv_in": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "idf_attention": (ci, [C.POINTER(AttnArgs), vp]),
     "idf_groupnorm_ws_floats": (ll, [ci, ci]),
@@ -101,7 +107,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.idf_abi_version() != 3:
+    if lib.idf_abi_version() != 4:
         raise RuntimeError("libidf_gfx950.so ABI version mismatch")
     _lib = lib
     return lib

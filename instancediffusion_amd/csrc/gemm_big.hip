@@ -903,11 +903,15 @@ BigSched& big_sched() {
       return (v < lo || v > hi) ? dflt : v;
     };
     BigSched c;
-    c.walk = env("IDF_BIG_WALK", 0, 0, 1);
+    // measured defaults (profiles/r04_big_sched_walk_dephase_epivm.log, all bit-identical): the chunked walk pays only when
+    // an m-tile has >= 32 n-tiles (N = 10240: +6.7 %; -4 ... -18 % on the narrower launches) -> walk = 2 (automatic);
+    // the counted wait behind the epilogue is +0.3 ... +1.6 % on the K <= 640 launches and +-0 elsewhere -> on;
+    // the de-phased start is +0 ... +4 % on two launches and -4 ... -20 % on the long-K ones -> off.
+    c.walk = env("IDF_BIG_WALK", 2, 0, 2);
     c.dephase = env("IDF_BIG_DEPHASE", 0, 0, 16);
     c.dephase_min_rounds = env("IDF_BIG_DEPHASE_MIN_ROUNDS", 8, 1, 1 << 20);
     c.dephase_epi_cycles = env("IDF_BIG_DEPHASE_EPI", 6000, 0, 1 << 20);
-    c.epi_vmcnt = env("IDF_BIG_EPIVM", 0, 0, 1);
+    c.epi_vmcnt = env("IDF_BIG_EPIVM", 1, 0, 1);
     return c;
   }();
   return sc;
@@ -941,7 +945,7 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   {                                                       // schedule knobs (all bit-identical; see the kernel)
     const BigSched& sc = big_sched();
     const int rounds = (tiles + slots - 1) / slots;
-    q.tile_walk = (!SPLIT && sc.walk) ? 1 : 0;
+    q.tile_walk = (!SPLIT && (sc.walk == 1 || (sc.walk == 2 && p.N / BN >= 32))) ? 1 : 0;
     q.epi_vmcnt = sc.epi_vmcnt;
     q.dephase = 0; q.dephase_units = 0;
     if (!SPLIT && sc.dephase > 1 && rounds >= sc.dephase_min_rounds) {

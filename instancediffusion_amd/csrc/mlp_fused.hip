@@ -27,6 +27,7 @@
 // summation order of the second GEMM.  LDS: 2 x 61 KB ring + 8 KB exchange + 16 KB epilogue staging = 146 KB.
 // Roofline: MFMA-bound, 2 * M * (2560 * 320 + 320 * 1280) flops; HBM: 2 B in + 2 B out per element of x (+ residual read).
 #include "gemm_core.h"
+#include <cstdlib>
 
 using namespace idfcore;
 
@@ -58,8 +59,18 @@ __device__ __forceinline__ void mlp_dma16(const void* sbase /* wave-uniform */, 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_bytes), "s"(sbase) : "memory");
 }
 
+// Schedule details, each measured on its own in profiles/r04_mlp_variants.log (all variants bit-identical):
+//   * skewed fill (as in gemm_big.hip): an LDS-DMA piece holds the issuing wave ~60 cycles, 7-8 pieces per wave and chunk; the
+//     older waves 0-3 enqueue right behind the chunk's barrier, the younger waves 4-7 one piece per two MFMAs of their first
+//     product, so the two waves of a SIMD are not blocked at the same time (-2.6 %);
+//   * fragment reads ahead of their MFMAs: W1 fragments 4 steps, the fold constants under the last MFMAs of the first product,
+//     all ten W2 fragments before the exchange barrier (+-0: the compiler's own schedule already covered the LDS latency);
+//   * NOT kept: running the two waves of a SIMD half a chunk apart (group B = group A delayed by one barrier interval, the
+//     ring refilled in two parts with counted vmcnt waits): correct, 7 % SLOWER -- the two intervals are not balanced
+//     (20 MFMAs + the GELU against 10 MFMAs), so the VALU tail still found no partner.
 template <int DT>
 __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const int tiles) {
+  constexpr bool PF = true, SK = true;
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,6 +93,15 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
     const int src = (lane & 3) ^ ((row >> 2) & 3);
     w2_voff[t] = (unsigned)(row * p.ldw2 + src * 8) * 2u;
   }
+  // piece `idx` of this wave for chunk j: 0..4 = W1 K-tiles, 5..7 = W2 row groups (7 only on waves 0-3), 8 = constants (wave 7)
+  auto issue_piece = [&](int idx, int j, int slot) {
+    char* const base = smem + slot * SLOT_BYTES;
+    if (idx < 5) mlp_dma16(p.w1 + (size_t)j * 64 * p.ldw1 + idx * 64, w1_voff, lds_u32(base + idx * 8192 + wave * 1024));
+    else if (idx < 8) {
+      const int t = idx - 5;
+      if (wave + 8 * t < 20) mlp_dma16(p.w2p + j * 32, w2_voff[t], lds_u32(base + W1_BYTES + (wave + 8 * t) * 1024));
+    } else if (wave == 7) mlp_dma16(p.cd + (size_t)j * 128, (unsigned)((lane & 31) * 16), lds_u32(base + W1_BYTES + W2_BYTES));
+  };
   auto issue_chunk = [&](int j, int slot) {
     char* const base = smem + slot * SLOT_BYTES;
     const unsigned short* w1j = p.w1 + (size_t)j * 64 * p.ldw1;
@@ -131,24 +151,48 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const bool last = (j == MLP_NCH - 1) && (tile + G >= tiles);
-      if (!last) issue_chunk(j + 1 == MLP_NCH ? 0 : j + 1, (g + 1) & 1);
+      const int jn = j + 1 == MLP_NCH ? 0 : j + 1;
+      const bool late = SK && wave >= 4 && !last;                // this wave enqueues from inside its first product
+      if (!last && !late) issue_chunk(jn, (g + 1) & 1);
       const char* const sl = smem + (g & 1) * SLOT_BYTES;
 
       // ---- GEMM 1: the 32 x 32 pre-activation fragment of packed W1 rows 64 j + 32 wn ..: 20 k-steps, B operand = xf
       f32x16 acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+      const float* cdp = reinterpret_cast<const float*>(sl + W1_BYTES + W2_BYTES) + 32 * wn + 4 * hi;
+      f32x4 cv[2], cg[2], dv[2], dg[2];
       {
         const char* wb = sl + w1_row;
-        u32x4 wf[2];
-        wf[0] = *reinterpret_cast<const u32x4*>(wb + ((hi ^ sw1) << 4));
+        constexpr int DEPTH = PF ? 4 : 1;
+        u32x4 wf[DEPTH + 1];
+        auto rd = [&](int ks) {
+          const int kt = ks >> 2, c = 2 * (ks & 3) + hi;
+          return *reinterpret_cast<const u32x4*>(wb + kt * 8192 + ((c ^ sw1) << 4));
+        };
+#pragma unroll
+        for (int ks = 0; ks < DEPTH; ++ks) wf[ks] = rd(ks);
 #pragma unroll
         for (int ks = 0; ks < 20; ++ks) {
-          if (ks + 1 < 20) {
-            const int kt = (ks + 1) >> 2, c = 2 * ((ks + 1) & 3) + hi;
-            wf[(ks + 1) & 1] = *reinterpret_cast<const u32x4*>(wb + kt * 8192 + ((c ^ sw1) << 4));
+          if (ks + DEPTH < 20) wf[(ks + DEPTH) % (DEPTH + 1)] = rd(ks + DEPTH);
+          if (PF && ks == 14) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              cv[q] = *reinterpret_cast<const f32x4*>(cdp + 8 * q); cg[q] = *reinterpret_cast<const f32x4*>(cdp + 16 + 8 * q);
+              dv[q] = *reinterpret_cast<const f32x4*>(cdp + 64 + 8 * q); dg[q] = *reinterpret_cast<const f32x4*>(cdp + 80 + 8 * q);
+            }
           }
-          acc1 = Elem<DT>::mfma32(wf[ks & 1], xf[ks], acc1);
+          acc1 = Elem<DT>::mfma32(wf[ks % (DEPTH + 1)], xf[ks], acc1);
+          if (SK && (ks & 1) && (ks >> 1) < 9) {
+            if (late) issue_piece(ks >> 1, jn, (g + 1) & 1);
+          }
+        }
+      }
+      if (!PF) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          cv[q] = *reinterpret_cast<const f32x4*>(cdp + 8 * q); cg[q] = *reinterpret_cast<const f32x4*>(cdp + 16 + 8 * q);
+          dv[q] = *reinterpret_cast<const f32x4*>(cdp + 64 + 8 * q); dg[q] = *reinterpret_cast<const f32x4*>(cdp + 80 + 8 * q);
         }
       }
       // ---- LayerNorm fold + bias + GEGLU in registers: acc1[4 q + e] = pre[packed row 8 q + 4 hi + e][row l31]; rows 0..15 of
@@ -156,39 +200,41 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
       // {4 hi + e, 8 + 4 hi + e}, which (in this order) are the 8 k values of its half of the second GEMM's 16-wide k-step
       u32x4 hmine;
       {
-        const float* cdp = reinterpret_cast<const float*>(sl + W1_BYTES + W2_BYTES) + 32 * wn + 4 * hi;
         float o[8];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f32x4 cv = *reinterpret_cast<const f32x4*>(cdp + 8 * q), cg = *reinterpret_cast<const f32x4*>(cdp + 16 + 8 * q);
-          const f32x4 dv = *reinterpret_cast<const f32x4*>(cdp + 64 + 8 * q), dg = *reinterpret_cast<const f32x4*>(cdp + 80 + 8 * q);
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float val = fmaf(rstd, fmaf(nmu, cv[e], acc1[4 * q + e]), dv[e]);
-            const float gat = fmaf(rstd, fmaf(nmu, cg[e], acc1[4 * (q + 2) + e]), dg[e]);
+            const float val = fmaf(rstd, fmaf(nmu, cv[q][e], acc1[4 * q + e]), dv[q][e]);
+            const float gat = fmaf(rstd, fmaf(nmu, cg[q][e], acc1[4 * (q + 2) + e]), dg[q][e]);
             o[4 * q + e] = val * gelu_erf_f(gat);
           }
-        }
         hmine = pack8<DT>(o);
       }
       // ---- exchange with the other wave of this row group (it holds the other 16 intermediate columns of the chunk)
       *reinterpret_cast<u32x4*>(xch_mine) = hmine;
+      const char* w2b = sl + w2_row;
+      u32x4 w2f[2][5];
+      if (PF) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int a = 0; a < 5; ++a) w2f[kk][a] = *reinterpret_cast<const u32x4*>(w2b + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const u32x4 hpeer = *reinterpret_cast<const u32x4*>(xch_peer);
       // ---- GEMM 2: two k-steps (the fragment of wn = 0, then of wn = 1) x 5 output fragments
-      {
-        const char* wb = sl + w2_row;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const u32x4 hf = (kk == wn) ? hmine : hpeer;
-          u32x4 w2f[5];
+      for (int kk = 0; kk < 2; ++kk) {
+        const u32x4 hf = (kk == wn) ? hmine : hpeer;
+        if (!PF) {
 #pragma unroll
-          for (int a = 0; a < 5; ++a) w2f[a] = *reinterpret_cast<const u32x4*>(wb + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
-#pragma unroll
-          for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[a], hf, acc2[a]);
+          for (int a = 0; a < 5; ++a) w2f[kk][a] = *reinterpret_cast<const u32x4*>(w2b + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
         }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[kk][a], hf, acc2[a]);
       }
     }
 

@@ -43,6 +43,13 @@ def _round_up(x: int, m: int) -> int:
 GEGLU_PERIOD = int(os.environ.get("IDF_GEGLU_PERIOD", "32"))
 if GEGLU_PERIOD not in (32, 64):
     raise ValueError(f"IDF_GEGLU_PERIOD={GEGLU_PERIOD}: must be 32 or 64")
+# Fused GEGLU feed-forward (idf_mlp_geglu: one launch per MLP, the 4C-wide intermediate never reaches HBM) where the kernel
+# exists -- the C = 320 blocks -- and the statistics of its LayerNorm are at hand; IDF_MLP_FUSED=0: the two idf_gemm calls
+# (A/B switch; results equal up to the fp32 summation order of the second product).
+MLP_FUSED = os.environ.get("IDF_MLP_FUSED", "1")
+if MLP_FUSED not in ("0", "1"):
+    raise ValueError(f"IDF_MLP_FUSED={MLP_FUSED}: must be 0 or 1")
+MLP_FUSED = MLP_FUSED == "1" and GEGLU_PERIOD == 32
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, period: int = 64) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -184,7 +191,11 @@ class UNetEngine:
         g, b = norm.weight.detach().float(), norm.bias.detach().float()
         wp, dp = pack_geglu(w * g[None, :], ff.net[0].proj.bias.detach().float() + w @ b, GEGLU_PERIOD)
         w16 = self._w16(wp)
-        return dict(w1=w16, b1=self._f32(dp), c1=w16.float().sum(1).contiguous(), l2=self._lin(ff.net[2]))
+        f = dict(w1=w16, b1=self._f32(dp), c1=w16.float().sum(1).contiguous(), l2=self._lin(ff.net[2]))
+        C = w.shape[1]
+        if MLP_FUSED and hasattr(self.ops, "mlp_geglu") and self.ops.mlp_supported(128, C):
+            f["cd"], f["w2p"] = self.ops.mlp_pack(w16, f["c1"], f["b1"], f["l2"].w)
+        return f
 
     def _attn(self, a, norm, self_attn: bool):
         """Attention projections behind LayerNorm `norm` (applied to the QUERY side input; for self-attention also to K / V)."""
@@ -582,6 +593,8 @@ class UNetEngine:
         produced y: a GEGLU GEMM has 8-16 column tiles per row block, each of which would repeat the in-loop row sums --
         measured +15 % on those launches -- so here the separate 8-B-per-row pass is the cheaper form)."""
         ops = self.ops
+        if "w2p" in f and st is not None and LN_SELF_MODE != 2 and out_stats is None and ops.mlp_supported(M, C):
+            return ops.mlp_geglu(y, st, f["w1"], f["cd"], f["w2p"], f["l2"].b, y, gate=gate)
         mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True, geglu_period=GEGLU_PERIOD,
                        ln_row=(None if LN_SELF_MODE == 2 else st, f["c1"]))
         return ops.gemm(mid, f["l2"].w, y, bias=f["l2"].b, res=y, gate=gate, out_stats=out_stats)

@@ -153,6 +153,40 @@ class HipOps:
         _lib.check(self.lib.idf_gemm(C.byref(args), self._stream()), "idf_gemm")
         return out
 
+    # permutation of the k index inside every 16-group of the fused MLP's second weight (include/idf.h idf_mlp_geglu): an
+    # involution (it swaps positions 4..7 and 8..11)
+    MLP_W2_PERM = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+    @staticmethod
+    def mlp_supported(M: int, C: int) -> bool:
+        """Shapes idf_mlp_geglu takes (the 64 x 64-latent blocks: C = 320, whole 128-row tiles)."""
+        return C == 320 and M % 128 == 0
+
+    @classmethod
+    def mlp_pack(cls, w1p16, c1, d1, w2_16):
+        """Operand images of idf_mlp_geglu from the period-32-packed first projection (16-bit weight, fp32 row sums c1 and
+        bias / beta term d1) and the 16-bit second weight [C, 4C]: (cd [8C/64][128] fp32, w2p)."""
+        n2 = c1.numel()
+        cd = torch.cat([c1.float().view(n2 // 64, 64), d1.float().view(n2 // 64, 64)], dim=1).contiguous()
+        perm = torch.tensor(cls.MLP_W2_PERM, device=w2_16.device)
+        n, k = w2_16.shape
+        w2p = w2_16.view(n, k // 16, 16).index_select(2, perm).reshape(n, k).contiguous()
+        return cd, w2p
+
+    def mlp_geglu(self, x, stats, w1, cd, w2p, b2, out, *, gate=None):
+        """out = x + [gate *] FF(LN(x)) in one launch (idf_mlp_geglu); x / out [M, 320] views (may alias), stats [M, 2]."""
+        M, Cc = x.shape
+        assert self.mlp_supported(M, Cc) and out.shape == x.shape and x.stride(-1) == 1 and out.stride(-1) == 1
+        assert stats.is_contiguous() and stats.dtype == torch.float32 and stats.numel() == 2 * M
+        assert w1.shape == (8 * Cc, Cc) and w2p.shape == (Cc, 4 * Cc) and cd.is_contiguous() and cd.numel() == 16 * Cc
+        assert w1.stride(-1) == 1 and w2p.stride(-1) == 1 and b2.dtype == torch.float32 and cd.dtype == torch.float32
+        args = _lib.MlpArgs(x=x.data_ptr(), ldx=x.stride(0), ln_stats=stats.data_ptr(), w1=w1.data_ptr(), ldw1=w1.stride(0),
+                            cd=cd.data_ptr(), w2p=w2p.data_ptr(), ldw2=w2p.stride(0), b2=b2.data_ptr(),
+                            gate=None if gate is None else gate.data_ptr(), out=out.data_ptr(), ldo=out.stride(0), M=M, C=Cc,
+                            dtype=self.dt)
+        _lib.check(self.lib.idf_mlp_geglu(C.byref(args), self._stream()), "idf_mlp_geglu")
+        return out
+
     def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
         """x [B,H,W,Cin] view (channel-contiguous), w [Cout, 9*Cin]; out [B,Ho,Wo,Cout] 16-bit, or fp32 NCHW
         [B,n_valid,Ho,Wo] when ``n_valid`` > 0 (final conv)."""

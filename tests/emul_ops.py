@@ -106,6 +106,29 @@ class EmulOps:
             out_stats.reshape(-1, 2)[:, 1] = torch.rsqrt(o.var(-1, unbiased=False) + out_stats_eps)
         return out
 
+    # ---- fused GEGLU feed-forward (include/idf.h idf_mlp_geglu): the double un-packs the operand images and runs the two
+    # products the kernel fuses, rounding the intermediate to the storage type as the kernel does
+    @staticmethod
+    def mlp_supported(M, C):
+        from instancediffusion_amd.ops import HipOps
+        return HipOps.mlp_supported(M, C)
+
+    @staticmethod
+    def mlp_pack(w1p16, c1, d1, w2_16):
+        from instancediffusion_amd.ops import HipOps
+        return HipOps.mlp_pack(w1p16, c1, d1, w2_16)
+
+    def mlp_geglu(self, x, stats, w1, cd, w2p, b2, out, *, gate=None):
+        from instancediffusion_amd.ops import HipOps
+        self._count("mlp_geglu")
+        M, C = x.shape
+        assert self.mlp_supported(M, C) and cd.shape == (8 * C // 64, 128)
+        c1, d1 = cd[:, :64].reshape(-1), cd[:, 64:].reshape(-1)
+        perm = torch.tensor(HipOps.MLP_W2_PERM)                  # an involution: applying it again restores W2
+        w2 = w2p.view(C, 4 * C // 16, 16).index_select(2, perm).reshape(C, 4 * C)
+        mid = self.gemm(x, w1, torch.empty((M, 4 * C), dtype=self.dtype), bias=d1, geglu=True, geglu_period=32, ln_row=(stats, c1))
+        return self.gemm(mid, w2, out, bias=b2, res=x, gate=gate)
+
     def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
         self._count("conv3x3")
         B, H, W_, Cin = x.shape

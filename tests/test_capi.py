@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libidf_gfx950.so does not export {name}"
         assert name in _lib.SYMBOLS, f"_lib.SYMBOLS has no prototype for {name}"
-    assert lib.idf_abi_version() == 3
+    assert lib.idf_abi_version() == 4
     assert b"gfx950" in lib.idf_build_info()
 
 
@@ -83,10 +83,56 @@ def test_argument_validation_without_gpu():
     assert lib.idf_gemm(ctypes.byref(vt_args(epi=_lib.EPI_BIAS | _lib.EPI_LN_ROW | _lib.EPI_SILU)), None) == -1
     assert lib.idf_gemm(ctypes.byref(vt_args(out_stats=0x80000)), None) == -1
     assert lib.idf_gemm(ctypes.byref(vt_args(ln_stats_out=None)), None) == -1             # self-normalising fallback needs them
+    # a BIAS-only fused q | k | v call (no LN_ROW) is rejected during validation -- it used to fail in the two-GEMM
+    # fallback after the q | k GEMM had already been launched, i.e. depending on tuning mode and CU count
+    assert lib.idf_gemm(ctypes.byref(vt_args(epi=_lib.EPI_BIAS, ln_stats_out=None)), None) == -1
+    # fused GEGLU feed-forward (ABI 4): null / misaligned operands and shapes the kernel does not take, before any launch
+    def mlp_args(**kw):
+        m = _lib.MlpArgs(x=0x10000, ldx=320, ln_stats=0x20000, w1=0x30000, ldw1=320, cd=0x40000, w2p=0x50000, ldw2=1280,
+                         b2=0x60000, out=0x70000, ldo=320, M=256, C=320, dtype=0)
+        for k, v in kw.items():
+            setattr(m, k, v)
+        return m
+    assert lib.idf_mlp_geglu(None, None) == -1
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(cd=None)), None) == -1
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(dtype=7)), None) == -1
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(C=640, ldx=640, ldo=640, ldw1=640, ldw2=2560)), None) == -3   # only C = 320
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(M=200)), None) == -3                   # whole 128-row tiles only
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ldo=324)), None) == -2                 # 16-B row alignment
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ln_stats=0x20004)), None) == -2
+    assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ldw2=640)), None) == -1                # rows of W2 shorter than 4C
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
     assert lib.idf_set_tuning(2, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
     prev = lib.idf_set_tuning(1, 2)
     assert prev in (0, 1, 2, 3) and lib.idf_set_tuning(1, prev) == 2
+
+
+def test_fuser_type_values_of_the_reference_are_accepted():
+    """openaimodel.py:349 accepts gatedSA / gatedSA2 / gatedCA and attention.py:325 builds a GatedSelfAttentionDense whatever
+    the value: all three must construct the same network here."""
+    import torch
+    from instancediffusion_amd.host.config import instantiate_from_config, load_yaml
+    cfg = load_yaml(os.path.join(REPO, "configs", "test_box.yaml"))
+    keys = {}
+    for ft in ("gatedSA", "gatedSA2", "gatedCA"):
+        cfg["model"]["params"]["fuser_type"] = ft
+        with torch.device("meta"):
+            m = instantiate_from_config(cfg["model"])
+        keys[ft] = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert keys["gatedSA"] == keys["gatedSA2"] == keys["gatedCA"] and len(keys["gatedSA"]) == 1199
+
+
+def test_stale_tuning_values_in_the_environment_fall_back_to_the_default():
+    """IDF_ATTN2 / IDF_GEMM_BIG values outside the range idf_set_tuning accepts (e.g. an attention mode of ABI 2)
+    are ignored instead of selecting a kernel by accident."""
+    import subprocess
+    import sys
+    code = ("import instancediffusion_amd._lib as L; lib = L.load(); a = lib.idf_set_tuning(1, 1); b = lib.idf_set_tuning(0, 1); "
+            "print(a, b)")
+    env = dict(os.environ, IDF_ATTN2="9", IDF_GEMM_BIG="-5")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.strip().splitlines()[-1] == "1 1", out.stdout
 
 
 def test_schema_matches_reference():

@@ -845,6 +845,63 @@ def test_gemm_geglu_period32(ops, M, C, stats):
     assert torch.equal(outs[32], outs[64])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,gated,inplace", [(128, False, False), (4096, True, True), (65536 + 128, True, False), (524288, False, True)])
+def test_gemm_fused_mlp(M, gated, inplace, dtype):
+    """idf_mlp_geglu (mlp_fused.hip): LayerNorm -> GEGLU projection -> Linear -> [gated] residual of a C = 320 transformer block
+    in ONE launch (attention.py:36-63, call sites :309 / :337), against the fp32 chain LN -> Linear -> value * gelu(gate) ->
+    Linear -> x + gate * (...), and against the two idf_gemm calls it replaces (same operands, same rounding of the
+    intermediate to the 16-bit type: equal up to the fp32 summation order of the second product).  M = 128: one tile, 127
+    workgroups idle; 65664: a tile count that is not a multiple of the CU count; 524288: the 128-row forward, in place
+    (out aliases x, as the engine calls it).  The error is measured on the MLP's contribution out - x as well: next to the
+    residual it is small, and a relative error of the sum would hide it."""
+    import torch.nn.functional as F
+    from instancediffusion_amd.engine import pack_geglu
+    from instancediffusion_amd.ops import HipOps
+    ops = HipOps(dtype)
+    C, Hd = 320, 1280
+    gamma, beta = 1 + 0.2 * gen((C,), 301), 0.3 * gen((C,), 302)
+    w1, b1 = gen((2 * Hd, C), 303, C ** -0.5), 0.2 * gen((2 * Hd,), 304)
+    w2, b2 = gen((C, Hd), 305, Hd ** -0.5), 0.2 * gen((C,), 306)
+    rows = min(M, 8192)                                           # distinct rows; tiled over M (the reference is per row)
+    x = (gen((rows, C), 307) * 1.5 + 0.5 * gen((rows, 1), 308)).to(dtype)
+    x = x.repeat(M // rows + 1, 1)[:M].contiguous()
+    gate = torch.tensor([0.6], dtype=torch.float32) if gated else None
+    wp, dp = pack_geglu(w1 * gamma[None, :], b1 + w1 @ beta, 32)
+    w1_16, w2_16 = wp.to(dtype).cuda(), w2.to(dtype).cuda()
+    c1 = w1_16.float().sum(1).contiguous()
+    cd, w2p = ops.mlp_pack(w1_16, c1, dp.cuda(), w2_16)
+    xd = x.cuda()
+    st = ops.empty((M, 2), torch.float32)
+    ops.row_stats(xd, st, 1e-5)
+    # the two-GEMM path
+    mid = ops.gemm(xd, w1_16, ops.empty((M, Hd)), bias=dp.cuda(), geglu=True, geglu_period=32, ln_row=(st, c1))
+    two = ops.gemm(mid, w2_16, ops.empty((M, C)), bias=b2.cuda(), res=xd, gate=None if gate is None else gate.cuda())
+    del mid
+    # fused (in place: on a copy of x, so that `xd` stays the reference input)
+    xin = xd.clone() if inplace else xd
+    out = xin if inplace else ops.empty((M, C))
+    ops.mlp_geglu(xin, st, w1_16, cd, w2p, b2.cuda(), out, gate=None if gate is None else gate.cuda())
+    torch.cuda.synchronize()
+    # fp32 reference on the GPU (plain torch), distinct rows only
+    xr = xd[:rows].float()
+    h = F.layer_norm(xr, (C,), gamma.cuda(), beta.cuda(), 1e-5) @ w1.cuda().t() + b1.cuda()
+    mlp = (h[:, :Hd] * F.gelu(h[:, Hd:])) @ w2.cuda().t() + b2.cuda()
+    want = xr + (0.6 if gated else 1.0) * mlp
+    tol = {torch.bfloat16: (BF16_TOL, BF16_RMS_TOL, 1.5e-2), torch.float16: (2.0 ** -10, 4e-4, 2e-3)}[dtype]
+    err, mx = rel_rms(out[:rows], want), relmax(out[:rows], want)
+    err_mlp = rel_rms(out[:rows].float() - xr, want - xr)
+    err_two = rel_rms(two[:rows].float() - xr, want - xr)
+    same = rel_rms(out, two)
+    print(f"[parity] fused MLP M{M} {dtype} gate={gated} inplace={inplace}: out rel-rms {err:.3e} max-rel {mx:.3e}; MLP term alone "
+          f"{err_mlp:.3e} (two-GEMM path {err_two:.3e}); fused vs two-GEMM output {same:.3e}")
+    assert mx < tol[0] and err < tol[1]
+    assert err_mlp < tol[2] and err_mlp < 1.25 * err_two + 1e-4
+    assert same < tol[1] / 4
+    if M > rows:                                                  # every copy of a row gives the same bits, whatever tile / CU ran it
+        assert torch.equal(out[:rows], out[rows:2 * rows]) and torch.equal(out[:128], out[M - (M % rows or rows):][:128])
+
+
 @pytest.mark.parametrize("ratio", [10.0, 100.0])
 def test_gemm_layernorm_self_stats_large_mean_bound(ops, ratio):
     """the in-loop row sums of the persistent kernel are single-pass (sum x, sum x^2 by v_dot2c, fp32), so a row

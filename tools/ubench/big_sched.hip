@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
 #endif
   constexpr int NC = sizeof(cfgs) / sizeof(cfgs[0]);
   BigSched& sc = big_sched();
-  sc.dephase_min_rounds = 1;
+  sc.dephase_min_rounds = 1;                 // (sc.walk: 0 / 1 forced per setting below; the library default is 2 = automatic)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (const Shape& sh : shapes) {
     CoreParams p{};

@@ -176,7 +176,9 @@ def pmc_traffic(op_name, batch):
 
 
 def measure_roofline(engine, batch, fuser_on=True):
-    """One instrumented eager forward at the phase-1 batch: per-kernel-family durations from HIP events."""
+    """One instrumented eager forward at the phase-1 batch: per-kernel-family durations from HIP events.  The forward is a
+    PAIRED one ([cond | uncond] rows sharing latent and timestep), as every sampler forward of the timed region is: its
+    conditioning-free prefix runs on batch / 2 rows (engine.PAIR_HOIST), and the flops per row counted here are the executed ones."""
     dev = engine.device
     cond = engine._slots[batch]
     x = torch.randn(batch, 4, LATENT, LATENT, device=dev)
@@ -187,7 +189,7 @@ def measure_roofline(engine, batch, fuser_on=True):
         timer = OpTimer(real)
         engine.ops = timer
         try:
-            engine._forward_ops(x, t, cond, eps, fuser_on)
+            engine._forward_ops(x, t, cond, eps, fuser_on, paired=True)
         finally:
             engine.ops = real
     agg = timer.summary()
@@ -338,9 +340,9 @@ def main():
         rows = {True: 0, False: 0}                                # forward rows executed on this rank, fuser on / off
         real_forward = eng.forward_cond
 
-        def counting_forward(x, t, cond, out=None):
+        def counting_forward(x, t, cond, out=None, **kw):
             rows[eng.fuser_scale != 0.0] += int(x.shape[0])
-            return real_forward(x, t, cond, out=out)
+            return real_forward(x, t, cond, out=out, **kw)
         eng.forward_cond = counting_forward
 
         def one_step():

@@ -29,6 +29,7 @@
 // Numerics contract as before: fp32 scores / accumulators, P rounded to the 16-bit type before P.V, denominator sums the
 // rounded P.  Requirements (else IDF_ATTN2_UNSUPPORTED and the caller falls back): d in {24, 40, 56}, n % 8 == 0, aligned.
 #include "attn_core.h"
+#include <cstdlib>
 
 using namespace idfattn;
 
@@ -123,11 +124,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
   int L = blockIdx.x;
   {
     const int total = gridDim.x;
-    if (xcd_order && (total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+    if ((xcd_order & 1) && (total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
   }
   const int qb = L % nqb;
   const int h = (L / nqb) % p.H;
   const int b = L / (nqb * p.H);
+#ifdef IDF_ATTN_EXP
+  // experiment (tools/ubench/attn_harness.hip, env IDF_ATTN_EXP = sleep_units | prio << 8): the second workgroup of every CU
+  // (hardware blocks [256, 512) of the first dispatch round; later blocks inherit the slot phase of the one they replace) starts
+  // `sleep_units` x 64 cycles late and / or runs at s_setprio 1
+  {
+    const int exp = xcd_order >> 8;
+    if (((blockIdx.x >> 8) & 1) != 0) {
+      for (int i = 0; i < (exp & 0xff); ++i) __builtin_amdgcn_s_sleep(1);
+      if ((exp >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+    }
+  }
+#endif
 
   // zero the V^T ring once (pad rows of the O^T tile must be finite zeros), then the ones row and the ones fragment
   for (int i = tid; i < VST * VSZ / 2; i += NT) reinterpret_cast<unsigned*>(Vs)[i] = 0u;
@@ -560,6 +573,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_kernel(const AttnParams p, c
   }
 }
 
+inline int attn_exp() {
+#ifdef IDF_ATTN_EXP
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("IDF_ATTN_EXP"); v = e ? atoi(e) & 0xffff : 0; }
+  return v;
+#else
+  return 0;
+#endif
+}
+
 template <int DT>
 int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
   const int mode = idf_attn2_mode();
@@ -569,7 +592,7 @@ int launch_attn4(const AttnParams& p, int B, hipStream_t s) {
 #define IDF_ATTN4_CASE(KS, MT) \
   if (p.d == 8 * (2 * KS - 1)) { \
     if (nw == 8) hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1, 8>), grid, block, 0, s, p, nqb, 1); \
-    else hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1, 4>), grid, block, 0, s, p, nqb, mode == 3 ? 0 : 1); \
+    else hipLaunchKernelGGL((attn4_kernel<DT, KS, MT, 1, 4>), grid, block, 0, s, p, nqb, (mode == 3 ? 0 : 1) | (attn_exp() << 8)); \
     return idf_launch_status(); }
   IDF_ATTN4_CASE(2, 1)    // d = 24
   IDF_ATTN4_CASE(3, 2)    // d = 40

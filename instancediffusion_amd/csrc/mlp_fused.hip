@@ -68,6 +68,25 @@ __device__ __forceinline__ void mlp_dma16(const void* sbase /* wave-uniform */, 
 //   * NOT kept: running the two waves of a SIMD half a chunk apart (group B = group A delayed by one barrier interval, the
 //     ring refilled in two parts with counted vmcnt waits): correct, 7 % SLOWER -- the two intervals are not balanced
 //     (20 MFMAs + the GELU against 10 MFMAs), so the VALU tail still found no partner.
+// Optional per-segment cycle trace (a second library build with -DIDF_MLP_TRACE, read through idf_mlp_trace_read by
+// tools/ubench/mlp_harness.hip; the shipped library has none of it): s_memtime deltas of waves 0 and 4 of the first and of a
+// middle workgroup, summed over all chunks.  Segments: 0 vmcnt wait, 1 chunk barrier, 2 early LDS-DMA enqueue, 3 first
+// product (+ late enqueue), 4 fold + GEGLU + publish + W2 fragment reads, 5 exchange barrier, 6 second product, 7 tile
+// epilogue, 8 tile load, 9 number of chunks.
+#ifdef IDF_MLP_TRACE
+__device__ unsigned long long idf_mlp_trace_buf[4][10];
+#define MTR_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MTR(i) { const unsigned long long tr_now = __builtin_readcyclecounter(); tr_acc[i] += tr_now - tr_last; tr_last = tr_now; }
+#define MTR_COUNT(i) { tr_acc[i] += 1; }
+#define MTR_DUMP { const int trb = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1);                     \
+    if (trb >= 0 && lane == 0 && (wave == 0 || wave == 4)) { for (int i = 0; i < 10; ++i) idf_mlp_trace_buf[trb * 2 + (wave ? 1 : 0)][i] = tr_acc[i]; } }
+#else
+#define MTR_DECL
+#define MTR(i) {}
+#define MTR_COUNT(i) {}
+#define MTR_DUMP {}
+#endif
+
 template <int DT>
 __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const int tiles) {
   constexpr bool PF = true, SK = true;
@@ -128,6 +147,7 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
 
   issue_chunk(0, 0);
   int g = 0;                                                   // chunks consumed so far (ring slot = g & 1)
+  MTR_DECL
   for (; tile < tiles; tile += G) {
     const int m = tile * MLP_BM + wm * 32 + l31;               // the lane's row
     // activation rows: 20 B-operand fragments, elements 16 ks + 8 hi .. + 7 of row m
@@ -145,15 +165,19 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[a][r] = 0.0f;
 
+    MTR(8)
     for (int j = 0; j < MLP_NCH; ++j, ++g) {
       // chunk g has landed (this wave's pieces; the barrier publishes everyone's) and every wave is done with the other slot
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MTR(0)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      MTR(1) MTR_COUNT(9)
       const bool last = (j == MLP_NCH - 1) && (tile + G >= tiles);
       const int jn = j + 1 == MLP_NCH ? 0 : j + 1;
       const bool late = SK && wave >= 4 && !last;                // this wave enqueues from inside its first product
       if (!last && !late) issue_chunk(jn, (g + 1) & 1);
+      MTR(2)
       const char* const sl = smem + (g & 1) * SLOT_BYTES;
 
       // ---- GEMM 1: the 32 x 32 pre-activation fragment of packed W1 rows 64 j + 32 wn ..: 20 k-steps, B operand = xf
@@ -188,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
           }
         }
       }
+      MTR(3)
       if (!PF) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -222,8 +247,10 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
           for (int a = 0; a < 5; ++a) w2f[kk][a] = *reinterpret_cast<const u32x4*>(w2b + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MTR(4)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      MTR(5)
       const u32x4 hpeer = *reinterpret_cast<const u32x4*>(xch_peer);
       // ---- GEMM 2: two k-steps (the fragment of wn = 0, then of wn = 1) x 5 output fragments
 #pragma unroll
@@ -236,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
 #pragma unroll
         for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[kk][a], hf, acc2[a]);
       }
+      MTR(6)
     }
 
     // ---- tile epilogue: + b2, gate, + residual; 32 x 32 fragments through the wave's 2-KB slot so that a store instruction
@@ -284,7 +312,9 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
         *reinterpret_cast<u32x4*>(p.out + (size_t)(m_base + row) * p.ldo + n + sl_pc * 8) = *stg_at(row, sl_pc);
       }
     }
+    MTR(7)
   }
+  MTR_DUMP
 }
 
 template <int DT>
@@ -305,6 +335,12 @@ int launch_mlp320(const MlpParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef IDF_MLP_TRACE
+extern "C" int idf_mlp_trace_read(unsigned long long* host /* [4][10] */) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(idf_mlp_trace_buf), sizeof(idf_mlp_trace_buf));
+}
+#endif
 
 extern "C" int idf_mlp_geglu(const idf_mlp_args* a, void* stream) {
   if (!a) return IDF_E_ARG;

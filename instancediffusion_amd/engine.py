@@ -50,6 +50,14 @@ MLP_FUSED = os.environ.get("IDF_MLP_FUSED", "1")
 if MLP_FUSED not in ("0", "1"):
     raise ValueError(f"IDF_MLP_FUSED={MLP_FUSED}: must be 0 or 1")
 MLP_FUSED = MLP_FUSED == "1" and GEGLU_PERIOD == 32
+# Paired forwards (classifier-free guidance: rows [n, 2n) carry the SAME latent and timestep as rows [0, n) and differ only in
+# their conditioning): everything in front of the first block that reads the conditioning -- first conv, first ResBlock,
+# GroupNorm, proj_in and the first 64 x 64 self-attention with its out-projection -- is computed ONCE for the n distinct
+# rows and duplicated (exact: those layers see only (x, t)).  IDF_PAIR_HOIST=0 computes all 2n rows (A/B switch).
+PAIR_HOIST = os.environ.get("IDF_PAIR_HOIST", "1")
+if PAIR_HOIST not in ("0", "1"):
+    raise ValueError(f"IDF_PAIR_HOIST={PAIR_HOIST}: must be 0 or 1")
+PAIR_HOIST = PAIR_HOIST == "1"
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, period: int = 64) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -599,11 +607,21 @@ class UNetEngine:
                        ln_row=(None if LN_SELF_MODE == 2 else st, f["c1"]))
         return ops.gemm(mid, f["l2"].w, y, bias=f["l2"].b, res=y, gate=gate, out_stats=out_stats)
 
-    def _st(self, p, x, cond: Cond, fuser_on: bool):
+    def _dup(self, t: torch.Tensor, role: str) -> torch.Tensor:
+        """[n, ...] -> [2n, ...]: both halves a copy of t (the second half of a paired forward)."""
+        n = t.shape[0]
+        out = self.buf(role, (2 * n,) + tuple(t.shape[1:]), t.dtype)
+        out[:n].copy_(t)
+        out[n:].copy_(t)
+        return out
+
+    def _st(self, p, x, cond: Cond, fuser_on: bool, dup: bool = False):
         """SpatialTransformer (attention.py:366-379).  No LayerNorm kernel runs: every GEMM that reads LN(y) reads y itself
         against gamma-folded weights and applies (mu, rstd) in its epilogue.  The q/k and cross-q projections sum their A
         rows in their own K loop (the q/k one hands the statistics to the transposed-V projection); the GEGLU GEMMs take
-        them from the out-projection that wrote y (``out_stats``: an 8-B-per-row pass inside that idf_gemm call)."""
+        them from the out-projection that wrote y (``out_stats``: an 8-B-per-row pass inside that idf_gemm call).
+        ``dup``: x holds the n DISTINCT rows of a paired forward (see PAIR_HOIST); the block's input and its residual stream
+        are duplicated to 2n rows behind the self-attention, the last layer that does not read the conditioning."""
         ops = self.ops
         B, H, W, C = x.shape
         N, M = H * W, B * H * W
@@ -615,6 +633,16 @@ class UNetEngine:
         # --- self attention (attention.py:334): LN norm1
         att = self._self_attn(p["attn1"], y, st, B, N, C)
         ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y, out_stats=pre)
+        if dup:
+            x, y = self._dup(x, "st.x_in2"), self._dup(y.view(B, N, C), "st.x2").view(2 * M, C)
+            if pre is not None:
+                st = self._dup(st.view(B, N, 2), "st.stats2").view(2 * M, 2)
+                pre = st
+                ffs = st if ffs is not None else None
+            else:
+                st = self.buf("st.stats", (2 * M, 2), torch.float32)
+                ffs = st if ffs is not None else None
+            B, M = 2 * B, 2 * M
         # --- gated self attention over [visual ; grounding tokens] (attention.py:304-311): LN fuser.norm1 / norm2
         i = p["idx"]
         if fuser_on:
@@ -636,7 +664,7 @@ class UNetEngine:
         ops.gemm(y, p["proj_out"].w, x.view(M, C), bias=p["proj_out"].b, res=x.view(M, C))
         return x
 
-    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role):
+    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role, dup_st: bool = False):
         for j, p in enumerate(layers):
             k = p["kind"]
             if k == "conv_in":
@@ -645,7 +673,7 @@ class UNetEngine:
             elif k == "res":
                 h = self._res(p, h, emb_all, out_role)
             elif k == "st":
-                h = self._st(p, h, cond, fuser_on)
+                h = self._st(p, h, cond, fuser_on, dup=dup_st)
             elif k == "down":
                 B, H, W, C = h.shape
                 h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role, (B, (H + 1) // 2, (W + 1) // 2, C)),
@@ -656,10 +684,16 @@ class UNetEngine:
                                      bias=p["conv"].b, upsample=1)
         return h
 
-    def _forward_ops(self, x: torch.Tensor, t_f32: torch.Tensor, cond: Cond, eps: torch.Tensor, fuser_on: bool):
-        """Enqueue one UNet forward (openaimodel.py:482-563).  x [B,4,H,W] fp32, t_f32 [B], eps [B,4,H,W] fp32."""
+    def _forward_ops(self, x: torch.Tensor, t_f32: torch.Tensor, cond: Cond, eps: torch.Tensor, fuser_on: bool,
+                     paired: bool = False):
+        """Enqueue one UNet forward (openaimodel.py:482-563).  x [B,4,H,W] fp32, t_f32 [B], eps [B,4,H,W] fp32.
+        ``paired``: rows [B/2, B) repeat the latent and timestep of rows [0, B/2) (see PAIR_HOIST)."""
         ops = self.ops
         B = x.shape[0]
+        # the hoist needs the reference layout: input block 0 = first conv, input block 1 = ResBlock + SpatialTransformer
+        hoist = (paired and PAIR_HOIST and B % 2 == 0 and len(self.in_blocks) > 1
+                 and [p["kind"] for p in self.in_blocks[0]] == ["conv_in"] and [p["kind"] for p in self.in_blocks[1]] == ["res", "st"])
+        n = B // 2
         mc = self.model.model_channels
         te = ops.timestep_embedding(t_f32, self.buf("temb.sin", (B, mc)))
         e1 = ops.gemm(te, self.te0.w, self.buf("temb.1", (B, 4 * mc)), bias=self.te0.b, act="silu")
@@ -668,6 +702,14 @@ class UNetEngine:
         hs = []
         h = None
         for i, layers in enumerate(self.in_blocks):
+            if hoist and i == 0:
+                h = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in0.half")
+                hs.append(self._dup(h, "in0"))
+                continue
+            if hoist and i == 1:
+                h = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in1.half", dup_st=True)
+                hs.append(h)
+                continue
             h = self._run_block(layers, h, x, emb_all, cond, fuser_on, f"in{i}")
             hs.append(h)
         h = self._run_block(self.mid_block, h, x, emb_all, cond, fuser_on, "mid")
@@ -713,30 +755,32 @@ class UNetEngine:
         self._slot_bound[B] = slot.uid
         return slot
 
-    def forward_cond(self, x: torch.Tensor, t: torch.Tensor, cond: Cond, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """eps = UNet(x, t | cond).  The launch sequence is captured once per (batch, resolution, fuser on/off)
-        into a hipGraph over static buffers and replayed; conditioning is copied into a static slot when it changes."""
+    def forward_cond(self, x: torch.Tensor, t: torch.Tensor, cond: Cond, out: Optional[torch.Tensor] = None,
+                     paired: bool = False) -> torch.Tensor:
+        """eps = UNet(x, t | cond).  The launch sequence is captured once per (batch, resolution, fuser on/off, paired)
+        into a hipGraph over static buffers and replayed; conditioning is copied into a static slot when it changes.
+        ``paired``: the caller guarantees x[B/2:] == x[:B/2] and t[B/2:] == t[:B/2] (a [cond | uncond] guidance batch)."""
         B, Cx, H, W = x.shape
         assert cond.B == B
         fuser_on = self.fuser_scale != 0.0
-        key = (B, H, W, fuser_on)
+        key = (B, H, W, fuser_on, bool(paired))
         x_s = self.buf("io.x", x.shape, torch.float32)
         t_s = self.buf("io.t", (B,), torch.float32)
         eps_s = self.buf("io.eps", (B, self.n_out, H, W), torch.float32)
         x_s.copy_(x)
         t_s.copy_(t)
         if not self.use_graphs:
-            self._forward_ops(x_s, t_s, cond, eps_s, fuser_on)
+            self._forward_ops(x_s, t_s, cond, eps_s, fuser_on, paired)
         else:
             slot = self._bind(cond)
             graph = self._graphs.get(key)
             if graph is None:
                 # eager warm-up sizes every buffer, then capture the identical launch sequence
-                self._forward_ops(x_s, t_s, slot, eps_s, fuser_on)
+                self._forward_ops(x_s, t_s, slot, eps_s, fuser_on, paired)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self._forward_ops(x_s, t_s, slot, eps_s, fuser_on)
+                    self._forward_ops(x_s, t_s, slot, eps_s, fuser_on, paired)
                 self._graphs[key] = graph
             graph.replay()
         if out is None:

@@ -94,7 +94,7 @@ class _PLMSBase(object):
         if guided:
             xx = torch.cat([x, x], 0)
             t = torch.full((2 * n,), float(step), device=x.device, dtype=torch.float32)
-            e2 = eng.forward_cond(xx, t, cond_pair, out=eng.buf("smp.eps2", xx.shape, torch.float32))
+            e2 = eng.forward_cond(xx, t, cond_pair, out=eng.buf("smp.eps2", xx.shape, torch.float32), paired=True)
             return eng.ops.cfg_combine(e2[:n], e2[n:], guidance_scale, eng.ops.empty(x.shape, torch.float32))
         t = torch.full((n,), float(step), device=x.device, dtype=torch.float32)
         return eng.forward_cond(x, t, cond_pair)

@@ -192,3 +192,41 @@ def test_fused_qkv_projection_equals_the_two_gemm_form():
         want = ref_cpu.unet_forward(sd, cfg, x, t.long(), ctx, objs)
     assert cases.rel_rms(outs[0], outs[1]) < 1e-5
     assert cases.rel_rms(outs[0], want) < 3e-4
+
+
+@pytest.mark.parametrize("fuser", [True, False])
+def test_paired_forward_hoists_the_conditioning_free_prefix_exactly(fuser, monkeypatch):
+    """A guidance batch [cond | uncond] carries the same latent and timestep in both halves: with ``paired=True`` the engine
+    runs the first conv, the first ResBlock and the first block's self-attention ONCE for the n distinct rows and duplicates
+    them behind the last layer that does not read the conditioning (engine.PAIR_HOIST).  Exact: the same bits as the forward
+    over all 2n rows (batch-invariant emulator), with half the attention rows in that first self-attention; also with the
+    fuser switched off (alpha = 0 stage), and equal to the CPU oracle."""
+    from oracle import ref_cpu
+    from instancediffusion_amd import engine as engine_mod, synth
+    from instancediffusion_amd.engine import Cond
+    cfg = cases.cfg_for("test_box.yaml", "mid")
+    model = build_model(cfg)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(33)
+    gb = synth.make_grounding_batch(2, synth.random_boxes(3, g), g)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    ctx, uc = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
+    t = torch.tensor([700.0, 300.0])
+    gi = GroundingNetInput()
+    grounding = gi.prepare(gb)
+    outs, rows = [], []
+    with torch.no_grad():
+        for hoist in (True, False):
+            monkeypatch.setattr(engine_mod, "PAIR_HOIST", hoist)
+            eng = UNetEngine(model, ops=EmulOps(torch.float32, batch_invariant=True), use_graphs=False)
+            if not fuser:
+                eng.set_fuser_scale(0.0)
+            pair = Cond.cat([eng.prepare_cond(ctx, grounding), eng.prepare_cond(uc, gi.get_null_input(batch=2))])
+            r0 = eng.ops.rows.get("attention", 0)
+            outs.append(eng.forward_cond(torch.cat([x, x]), torch.cat([t, t]), pair, paired=True))
+            rows.append(eng.ops.rows["attention"] - r0)
+        objs, _ = ref_cpu.unifusion(sd, cfg, ref_cpu.prepare_grounding(gb))
+        want = ref_cpu.unet_forward(sd, cfg, x, t.long(), ctx, objs, fuser_scale=1.0 if fuser else 0.0)
+    assert torch.equal(outs[0], outs[1]), "the hoisted prefix must give the bits of the full-width forward"
+    assert rows[0] == rows[1] - 2, (rows, "one self-attention launch over n = 2 instead of 2n = 4 rows")
+    assert cases.rel_rms(outs[0][:2], want) < 3e-4

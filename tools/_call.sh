@@ -1,2 +1,6 @@
-L=instancediffusion_amd
-for r in 1 2; do timeout 200 tools/ubench/attn_harness $L/libidf_attn_v0.so 128 1 $L/libidf_attn_v1.so $L/libidf_attn_v4a1.so $L/libidf_attn_v4a2.so $L/libidf_attn_v4a3.so 2>&1 | grep -E "d=40" ; done
+echo "== bench, pair hoist on (default)"
+timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-ref-batch-leg --no-roofline 2>/dev/null | cut -c1-260
+echo "== bench, IDF_PAIR_HOIST=0"
+IDF_PAIR_HOIST=0 timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-ref-batch-leg --no-roofline 2>/dev/null | cut -c1-260
+echo "== parity"
+timeout 900 python -m pytest tests/test_engine_gpu.py tests/test_samplers_gpu.py -q -s -m gpu -p no:cacheprovider -k "not s50 or headline" 2>&1 | grep -E "parity|passed|failed|Error|error" | cut -c1-330

@@ -7,6 +7,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/ubench/mlp_harness.hip -Linstancediffusion_amd -l:libidf_gfx950.so \
 //         -Wl,-rpath,'$ORIGIN/../../instancediffusion_amd' -o tools/ubench/mlp_harness
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -157,6 +158,22 @@ int main(int argc, char** argv) {
       const double flop = 2.0 * Mt * ((double)N1 * C + (double)C * H);
       printf("    M %6d: fused %8.1f us (%6.1f TF)   two gemms %8.1f us (%6.1f TF)   %+5.1f %%\n", Mt, tf[1], flop / tf[1] * 1e-6, tg[1],
              flop / tg[1] * 1e-6, (tg[1] / tf[1] - 1.0) * 100.0);
+      // a -DIDF_MLP_TRACE build of the library exports the cycle trace of the last fused launch
+      if (auto rd = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "idf_mlp_trace_read")) {
+        fused(Mt, dout); hipDeviceSynchronize();
+        unsigned long long tr[4][10];
+        if (rd(&tr[0][0]) == 0) {
+          const char* who[4] = {"wg0 wave0", "wg0 wave4", "wgM wave0", "wgM wave4"};
+          for (int w = 0; w < 4; ++w) {
+            const double nc = (double)tr[w][9];
+            if (nc == 0) continue;
+            double per = 0; for (int i = 0; i < 7; ++i) per += tr[w][i] / nc;
+            printf("      %s per chunk: vmwait %5.0f barrier %5.0f fill %5.0f gemm1 %5.0f geglu %5.0f xbarrier %5.0f gemm2 %5.0f = %5.0f cycles "
+                   "(1920 = pipe full) | per tile: epilogue %6.0f load %6.0f\n", who[w], tr[w][0] / nc, tr[w][1] / nc, tr[w][2] / nc, tr[w][3] / nc,
+                   tr[w][4] / nc, tr[w][5] / nc, tr[w][6] / nc, per, tr[w][7] / (nc / 40), tr[w][8] / (nc / 40));
+          }
+        }
+      }
     }
     hipFree(dx); hipFree(dout); hipFree(dout2); hipFree(dmid); hipFree(dw1); hipFree(dw2); hipFree(dw2p);
     hipFree(dst); hipFree(dc); hipFree(dd); hipFree(dcd); hipFree(db2); hipFree(dgate);

@@ -112,25 +112,34 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
     const int src = (lane & 3) ^ ((row >> 2) & 3);
     w2_voff[t] = (unsigned)(row * p.ldw2 + src * 8) * 2u;
   }
-  // piece `idx` of this wave for chunk j: 0..4 = W1 K-tiles, 5..7 = W2 row groups (7 only on waves 0-3), 8 = constants (wave 7)
+  // piece `idx` of this wave for chunk j, in the order they are enqueued (= the order they land): 0 = the fold constants
+  // (wave 7 only), 1..5 = W1 K-tiles, 6..8 = W2 row groups (8 only on waves 0-3).  The W2 pieces are the YOUNGEST: the chunk's
+  // first wait (W1 + constants landed) lets them stay in flight, they are waited for at the exchange barrier.
   auto issue_piece = [&](int idx, int j, int slot) {
     char* const base = smem + slot * SLOT_BYTES;
-    if (idx < 5) mlp_dma16(p.w1 + (size_t)j * 64 * p.ldw1 + idx * 64, w1_voff, lds_u32(base + idx * 8192 + wave * 1024));
-    else if (idx < 8) {
-      const int t = idx - 5;
+    if (idx == 0) {
+      if (wave == 7) mlp_dma16(p.cd + (size_t)j * 128, (unsigned)((lane & 31) * 16), lds_u32(base + W1_BYTES + W2_BYTES));
+    } else if (idx < 6) {
+      mlp_dma16(p.w1 + (size_t)j * 64 * p.ldw1 + (idx - 1) * 64, w1_voff, lds_u32(base + (idx - 1) * 8192 + wave * 1024));
+    } else {
+      const int t = idx - 6;
       if (wave + 8 * t < 20) mlp_dma16(p.w2p + j * 32, w2_voff[t], lds_u32(base + W1_BYTES + (wave + 8 * t) * 1024));
-    } else if (wave == 7) mlp_dma16(p.cd + (size_t)j * 128, (unsigned)((lane & 31) * 16), lds_u32(base + W1_BYTES + W2_BYTES));
+    }
   };
   auto issue_chunk = [&](int j, int slot) {
-    char* const base = smem + slot * SLOT_BYTES;
-    const unsigned short* w1j = p.w1 + (size_t)j * 64 * p.ldw1;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) mlp_dma16(w1j + t * 64, w1_voff, lds_u32(base + t * 8192 + wave * 1024));
-    const unsigned short* w2j = p.w2p + j * 32;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-      if (wave + 8 * t < 20) mlp_dma16(w2j, w2_voff[t], lds_u32(base + W1_BYTES + (wave + 8 * t) * 1024));
-    if (wave == 7) mlp_dma16(p.cd + (size_t)j * 128, (unsigned)((lane & 31) * 16), lds_u32(base + W1_BYTES + W2_BYTES));
+    for (int idx = 0; idx < 9; ++idx) issue_piece(idx, j, slot);
+  };
+  // counted waits (vector memory operations retire in order): "W1 + constants of this chunk landed" leaves this wave's W2
+  // pieces in flight; "W2 of this chunk landed" leaves the pieces of the NEXT chunk, all enqueued by then, in flight
+  auto wait_w1 = [&]() {
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  };
+  auto wait_w2 = [&](bool next_in_flight) {
+    if (!next_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wave < 4 || wave == 7) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   };
 
   // ---- fragment addressing
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
     MTR(8)
     for (int j = 0; j < MLP_NCH; ++j, ++g) {
       // chunk g has landed (this wave's pieces; the barrier publishes everyone's) and every wave is done with the other slot
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_w1();
       MTR(0)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -239,30 +248,26 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
       // ---- exchange with the other wave of this row group (it holds the other 16 intermediate columns of the chunk)
       *reinterpret_cast<u32x4*>(xch_mine) = hmine;
       const char* w2b = sl + w2_row;
+      // ---- GEMM 2: two k-steps x 5 output fragments.  The k-step of the wave's OWN fragment (k-step wn) needs nothing from the
+      // other wave: its 5 MFMAs are issued BEFORE the exchange barrier and run while the wave waits there (cycle trace,
+      // profiles/r04_mlp_trace_*.log: ~800 cycles per chunk at that barrier on the waves that enqueue early); the peer's
+      // k-step follows behind it.  (The two waves of a row group therefore add their two k-steps in opposite orders.)
       u32x4 w2f[2][5];
-      if (PF) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int a = 0; a < 5; ++a) w2f[kk][a] = *reinterpret_cast<const u32x4*>(w2b + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
-      }
+        for (int a = 0; a < 5; ++a) w2f[kk][a] = *reinterpret_cast<const u32x4*>(w2b + a * 2048 + (((2 * (kk ^ wn) + hi) ^ sw2) << 4));
+#pragma unroll
+      for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[0][a], hmine, acc2[a]);       // w2f[0] = k-step wn
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_w2(!last);
       MTR(4)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       MTR(5)
       const u32x4 hpeer = *reinterpret_cast<const u32x4*>(xch_peer);
-      // ---- GEMM 2: two k-steps (the fragment of wn = 0, then of wn = 1) x 5 output fragments
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const u32x4 hf = (kk == wn) ? hmine : hpeer;
-        if (!PF) {
-#pragma unroll
-          for (int a = 0; a < 5; ++a) w2f[kk][a] = *reinterpret_cast<const u32x4*>(w2b + a * 2048 + (((2 * kk + hi) ^ sw2) << 4));
-        }
-#pragma unroll
-        for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[kk][a], hf, acc2[a]);
-      }
+      for (int a = 0; a < 5; ++a) acc2[a] = Elem<DT>::mfma32(w2f[1][a], hpeer, acc2[a]);       // w2f[1] = k-step wn ^ 1
       MTR(6)
     }
 

@@ -65,9 +65,15 @@ __device__ __forceinline__ void mlp_dma16(const void* sbase /* wave-uniform */, 
 //     product, so the two waves of a SIMD are not blocked at the same time (-2.6 %);
 //   * fragment reads ahead of their MFMAs: W1 fragments 4 steps, the fold constants under the last MFMAs of the first product,
 //     all ten W2 fragments before the exchange barrier (+-0: the compiler's own schedule already covered the LDS latency);
-//   * NOT kept: running the two waves of a SIMD half a chunk apart (group B = group A delayed by one barrier interval, the
-//     ring refilled in two parts with counted vmcnt waits): correct, 7 % SLOWER -- the two intervals are not balanced
-//     (20 MFMAs + the GELU against 10 MFMAs), so the VALU tail still found no partner.
+//   * the k-step of the second product on the wave's own fragment is issued before the exchange barrier, and the chunk's two
+//     waits are counted (W1 + constants before the first product, W2 at the exchange barrier): +-0 (r04_mlp_split_waits.log);
+//   * NOT kept: running the two waves of a SIMD out of phase, so that one wave's VALU step (fold + GELU, ~850 cycles per
+//     chunk with the pipe idle: cycle trace r04_mlp_trace_*.log) meets the other's MFMAs -- as two barrier intervals per chunk
+//     (group B = group A delayed by one interval; ring refilled in two parts): 7 % SLOWER; as three balanced intervals
+//     (first product | GELU + own k-step | partner's k-step): 14 % SLOWER (r04_mlp_phase_shift_*.log,
+//     r04_mlp_three_interval_rejected.log; both bit-exact).  Two accumulator chains in the first product: spills, -12 %.
+//     Lock step is what this pipe likes: both waves of a SIMD in the same MFMA phase interleave perfectly, and a barrier
+//     costs least when everybody arrives together.
 // Optional per-segment cycle trace (a second library build with -DIDF_MLP_TRACE, read through idf_mlp_trace_read by
 // tools/ubench/mlp_harness.hip; the shipped library has none of it): s_memtime deltas of waves 0 and 4 of the first and of a
 // middle workgroup, summed over all chunks.  Segments: 0 vmcnt wait, 1 chunk barrier, 2 early LDS-DMA enqueue, 3 first

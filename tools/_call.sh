@@ -1,2 +1,1 @@
-for r in 1 2; do timeout 120 tools/ubench/mlp_harness 5 2>&1 | grep -E "^\[|fused|M [0-9]"; done
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -s -m gpu -p no:cacheprovider -k "fused_mlp" 2>&1 | grep -E "parity|passed|failed|Error|error" | cut -c1-300
+for v in 3 1 3 1; do echo "== IDF_MLP_V=$v"; IDF_MLP_V=$v timeout 120 tools/ubench/mlp_harness 5 2>&1 | grep -E "^\[|fused|M [0-9]"; done

@@ -114,6 +114,125 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
   }
 }
 
+// First conv on the matrix cores (round 4; Cin = 4, Cout = 320: the UNet's).  The quad kernel above is VALU-bound: 12 GFLOP of
+// fp32 FMAs per 128-row launch = 96 us of pure issue, 309 us measured, against a 67-us HBM bound on the 335 MB it writes.
+// As an implicit GEMM the work is M = B H W pixels x N = 320 x K = 36 -- nothing for the MFMA pipe -- but the operands are fp32
+// and the layer feeds everything else, so the product is kept at fp32-class accuracy by splitting BOTH operands into a bf16
+// head and a bf16 tail (x = xh + xl, w = wh + wl, each exact to 2^-17 relative) and summing xh wh + xh wl + xl wh on the
+// MFMAs: K = 3 x 36 = 108 (+ 4 zero columns = 7 k-steps of 16), error ~2^-16 of a product, below the rounding of the 16-bit
+// output.  One persistent 512-thread workgroup per CU: the split weight image [320][wh | wl | wh] lives in LDS for the whole
+// launch (75 KB, 240-B rows: an odd number of 16-B slots, conflict-free fragment reads); per 256-pixel tile the workgroup
+// gathers the 36 taps of its pixels from the NCHW latent (consecutive threads = consecutive pixels: coalesced), splits them and
+// writes the A tile [256][xh | xh | xl] (60 KB); 8 waves as 4 (64 pixels) x 2 (160 channels), 70 MFMAs per wave and tile; then
+// + bias and the 16-B stores.  Store-bound like the GEMM epilogues (~12 B/clk per CU): ~80 us per 128-row launch.
+constexpr int CIM_KP = 120;                       // padded K (elements) of an LDS row: 240 B
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void conv_in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, unsigned short* __restrict__ out,
+                                                              int B, int H, int W, int tiles) {
+  constexpr int Cout = 320, Cin = 4, BM = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned short cim_smem[];
+  unsigned short* const Wl = cim_smem;                         // [320][120]
+  unsigned short* const Al = cim_smem + Cout * CIM_KP;         // [256][120]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+  auto head = [](float v) { return Elem<IDF_BF16>::from_f32(v); };
+  auto tail = [](float v, unsigned short h) { return Elem<IDF_BF16>::from_f32(v - Elem<IDF_BF16>::to_f32(h)); };
+  // ---- weight image: w is [co][ci][ky][kx]; column t = tap * 4 + ci
+  for (int i = tid; i < Cout * CIM_KP; i += 512) Wl[i] = 0;
+  for (int i = tid; i < BM * CIM_KP; i += 512) Al[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < Cout * 36; i += 512) {
+    const int co = i / 36, k = i - co * 36;                    // k = ci * 9 + tap in the source
+    const int ci = k / 9, tap = k - ci * 9;
+    const float v = w[i];
+    const unsigned short h = head(v), l = tail(v, h);
+    unsigned short* row = Wl + co * CIM_KP + tap * 4 + ci;
+    row[0] = h; row[36] = l; row[72] = h;
+  }
+  const long long HW = (long long)H * W, P = (long long)B * HW;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    __syncthreads();                                           // the previous tile's fragment reads are done (and the images exist)
+    // ---- A tile: thread -> pixel tid & 255 and the 18 columns t = (tid >> 8) + 2 r (t = tap * 4 + ci): the pixel's coordinates
+    // are worked out once, the 18 gathers are independent loads in flight together
+    {
+      const int px = tid & 255, t0 = tid >> 8;
+      const long long m = (long long)tile * BM + px;
+      const bool live = m < P;
+      const int b = live ? (int)(m / HW) : 0;
+      const int rem = live ? (int)(m - (long long)b * HW) : 0;
+      const int y = rem / W, xx0 = rem - y * W;
+      const float* xb = x + (size_t)b * Cin * HW;
+      float v[18];
+#pragma unroll
+      for (int r = 0; r < 18; ++r) {
+        const int t = t0 + 2 * r;                               // t0 is 0 or 1: tap and channel follow from r and t0
+        const int tap = t >> 2, ci = t & 3;
+        const int yy = y + tap / 3 - 1, xx = xx0 + (tap - (tap / 3) * 3) - 1;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        v[r] = ok ? xb[(size_t)ci * HW + (size_t)yy * W + xx] : 0.0f;
+      }
+      unsigned short* row = Al + px * CIM_KP + t0;
+#pragma unroll
+      for (int r = 0; r < 18; ++r) {
+        const unsigned short h = head(v[r]), l = tail(v[r], h);
+        row[2 * r] = h; row[2 * r + 36] = h; row[2 * r + 72] = l;
+      }
+    }
+    __syncthreads();
+    // ---- 7 k-steps: acc[a][b][4 q + e] = D[channel 160 wn + 32 a + 8 q + 4 hi + e][pixel 64 wm + 32 b + l31]
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const unsigned short* wrow = Wl + (160 * wn + l31) * CIM_KP + 8 * hi;
+    const unsigned short* arow = Al + (64 * wm + l31) * CIM_KP + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+      u32x4 af[2], wf[5];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) af[b] = *reinterpret_cast<const u32x4*>(arow + b * 32 * CIM_KP + 16 * ks);
+#pragma unroll
+      for (int a = 0; a < 5; ++a) wf[a] = *reinterpret_cast<const u32x4*>(wrow + a * 32 * CIM_KP + 16 * ks);
+#pragma unroll
+      for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = Elem<IDF_BF16>::mfma32(wf[a], af[b], acc[a][b]);
+    }
+    // ---- + bias, 16-bit stores: two v_permlane32_swap per register pair leave a lane with 16 consecutive channels of its pixel
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      f32x4 bv[4];                                             // the lane's 16 consecutive channels of this fragment
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bias + 160 * wn + 32 * a + 16 * hi + 4 * j);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][e]), __float_as_uint(acc[a][b][8 + e]), false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][4 + e]), __float_as_uint(acc[a][b][12 + e]), false, false);
+          v[e] = __uint_as_float(s02[0]); v[4 + e] = __uint_as_float(s02[1]);
+          v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] += bv[j >> 2][j & 3];
+        const long long m = (long long)tile * BM + 64 * wm + 32 * b + l31;
+        if (m < P) {
+          unsigned short* o = out + (size_t)m * Cout + 160 * wn + 32 * a + 16 * hi;
+          *reinterpret_cast<u32x4*>(o) = pack8<DT>(v);
+          *reinterpret_cast<u32x4*>(o + 8) = pack8<DT>(v + 8);
+        }
+      }
+    }
+  }
+}
+
 __global__ void cfg_kernel(const float* __restrict__ ec, const float* __restrict__ eu, float g, float* __restrict__ et, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const float u = eu[i]; et[i] = u + g * (ec[i] - u); }
@@ -263,6 +382,26 @@ extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bia
   if (!x_nchw || !w || !bias || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8)) return IDF_E_ARG;
   if (!aligned16(out)) return IDF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (Cin == 4 && Cout == 320 && (dtype == IDF_BF16 || dtype == IDF_F16) && aligned16(bias)) {     // the UNet's first conv: matrix cores
+    const void* fn = dtype == IDF_F16 ? (const void*)conv_in_mfma_kernel<IDF_F16> : (const void*)conv_in_mfma_kernel<IDF_BF16>;
+    constexpr int smem_m = (320 + 256) * CIM_KP * 2;
+    static bool attr_m[2] = {false, false};
+    const int v = dtype == IDF_F16 ? 1 : 0;
+    if (!attr_m[v]) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_m);
+      if (e != hipSuccess) return (int)e;
+      attr_m[v] = true;
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const long long tiles = ((long long)B * H * W + 255) / 256;
+    if (tiles < (1ll << 31)) {
+      const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+      if (dtype == IDF_BF16) hipLaunchKernelGGL(conv_in_mfma_kernel<IDF_BF16>, grid, dim3(512), smem_m, s, x_nchw, w, bias, (unsigned short*)out, B, H, W, (int)tiles);
+      else hipLaunchKernelGGL(conv_in_mfma_kernel<IDF_F16>, grid, dim3(512), smem_m, s, x_nchw, w, bias, (unsigned short*)out, B, H, W, (int)tiles);
+      return idf_launch_status();
+    }
+  }
   const size_t smem = (size_t)9 * Cin * Cout * sizeof(float);
   if (smem > 144 * 1024) return IDF_E_UNSUPPORTED;               // gfx950: 160 KB LDS per CU
   if (smem > 64 * 1024) {                                        // e.g. the VAE decoder's 4 -> 512 first conv (72 KB)

@@ -37,6 +37,8 @@ def family(name):
         return "attention"
     if "splitk_reduce" in name:
         return "conv3x3"                         # only the 8x8-level convs / ff-out GEMMs split K; booked with the convs
+    if "mlp320_kernel" in name:                  # the fused GEGLU feed-forward: two dense products in one launch
+        return "gemm"
     if "gemm_kernel_big" in name:                # <DT, BM, BN, BKT, NSTG, CONV, SPLIT>
         a = _targs(name)
         return "conv3x3" if len(a) > 5 and a[5] in ("true", "1") else "gemm"

@@ -23,15 +23,19 @@ eng.use_graphs = False
 cond = eng.prepare_cond(inputs[0]["context"], inputs[0]["grounding_input"])
 x = torch.randn(batch, 4, 64, 64, device=dev)
 t = torch.full((batch,), 500.0, device=dev)
+# a guidance pair, as the samplers form their forwards (engine.PAIR_HOIST); PROFILE_UNPAIRED=1: `batch` distinct rows
+paired = batch % 2 == 0 and os.environ.get("PROFILE_UNPAIRED") != "1"
+if paired:
+    x[batch // 2:] = x[:batch // 2]
 for _ in range(2):
-    eng.forward_cond(x, t, cond)
+    eng.forward_cond(x, t, cond, paired=paired)
 torch.cuda.synchronize()
 
 
 class ShapeTimer(bench.OpTimer):
     def __getattr__(self, name):
         fn = getattr(self.ops, name)
-        if name not in ("gemm", "conv3x3", "attention", "groupnorm", "layernorm", "scaleu_concat", "row_stats"):
+        if name not in ("gemm", "conv3x3", "attention", "groupnorm", "layernorm", "scaleu_concat", "row_stats", "mlp_geglu", "conv_in"):
             return fn
 
         def timed(*a, **k):
@@ -49,6 +53,8 @@ class ShapeTimer(bench.OpTimer):
             elif name == "attention":
                 q = a[0]
                 key = f"attn Nq{q.shape[1]} C{q.shape[2]} n0={a[3]} n1={k.get('n1', 0)}"
+            elif name == "mlp_geglu":
+                key = f"mlp_geglu (fused GEGLU-in + ff-out) M{a[0].shape[0]} C{a[0].shape[1]}"
             else:
                 key = f"{name} {tuple(a[0].shape)}"
             self.records.append((key, self._work(name, a, k), s, e))
@@ -59,7 +65,7 @@ class ShapeTimer(bench.OpTimer):
 timer = ShapeTimer(eng.ops)
 real = eng.ops
 eng.ops = timer
-eng.forward_cond(x, t, cond)
+eng.forward_cond(x, t, cond, paired=paired)
 torch.cuda.synchronize()
 eng.ops = real
 tab = OrderedDict()

@@ -1,2 +1,2 @@
 timeout 60 tools/ubench/conv_in_bench
-timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py -q -s -m gpu -p no:cacheprovider -k "conv_in or (bench_width and bf16 and 128) or tiny_box" 2>&1 | grep -E "parity|passed|failed|Error|error" | cut -c1-300
+for mu in 64 96 64 96; do echo "== --max-units $mu"; timeout 600 python bench.py --max-units $mu --steps 1 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-ref-batch-leg --no-roofline 2>/dev/null | cut -c1-200; done

@@ -960,6 +960,7 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
 }  // namespace
 
 std::atomic<long long> idf_stat_big_launches{0};
+int idf_num_cu() { return num_cu(); }
 
 // Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
 int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out, int* parts_out,

@@ -491,6 +491,180 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_dma(const CoreParams p) {
   tile_epilogue<DT, BM, BN, WM, WN, LDS_BYTES>(p, acc, smem, m0, n0, bz, wm, wn, lane, wave);
 }
 
+// ---- K-loop variant 3 (round 4): the LATENCY kernel.  The launches the persistent kernel declines (a 2-row forward is ~250
+// GEMMs of 1-2 GFLOP and ~50 convs) spent their time in a serial chain: variant 2 keeps ONE K-tile in flight, so a K = 640
+// launch is ten back-to-back trips to L2 / HBM (~2 us each, cold weights) around 0.2 us of MFMA work -- 17-22 us per launch,
+// whatever the shape (profiles/r03_shape_profile_B2.log).  Same tile, LDS image, swizzle, fragment reads and epilogue as
+// variant 2, but an NS-stage ring with NS - 1 K-tiles in flight from the first instruction (all of K = 320), counted
+// s_waitcnt vmcnt instead of a drain per tile, and the conv activation tile arrives by LDS-DMA too (a lane whose tap is
+// padding reads a zero page, like the persistent kernel's loader).  LDS-DMA is inline assembly: with the builtin the
+// compiler orders every later ds_read behind ALL outstanding DMA.  One workgroup per CU (96-144 KB of LDS): meant for launches
+// of at most a few hundred tiles -- the dispatcher's rule is in launch().
+__device__ __attribute__((aligned(128))) unsigned short ring_zero_page[64];   // zero-initialised device memory
+
+__device__ __forceinline__ void ring_dma16(const void* addr /* per lane */, const void* lds_lane0) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_lane0);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(addr) : "memory");
+}
+// at most `ahead` K-tiles (PT LDS-DMA instructions of this wave each) may still be in flight behind the tile waited for
+template <int PT, int MAXA> __device__ __forceinline__ void ring_wait(int ahead) {
+  if constexpr (MAXA <= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    static_assert(MAXA * PT < 64, "vmcnt is a 6-bit field");
+    if (ahead >= MAXA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXA * PT) : "memory");
+    else ring_wait<PT, MAXA - 1>(ahead);
+  }
+}
+
+template <int DT, int BM, int BN, int WM, int WN, bool CONV, int NS>
+__global__ __launch_bounds__(256, 1) void gemm_kernel_ring(const CoreParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int RS = 64;                                // LDS row stride (elements) = BK, no padding
+  constexpr int BUF = (BM + BN) * RS;                   // elements per ring stage
+  constexpr int W_INST = BN / 8 / 4, A_INST = BM / 8 / 4;     // DMA instructions (8 rows each) per wave per tile
+  constexpr int PER_TILE = W_INST + A_INST;
+  constexpr int KLOOP_LDS = NS * BUF * 2;
+  constexpr int CSTAGE = 4 * WM * (WN + 4) * 4;
+  constexpr int LDS_BYTES = KLOOP_LDS > CSTAGE ? KLOOP_LDS : CSTAGE;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  static_assert(NS >= 3 && LDS_BYTES <= 160 * 1024, "ring must fit the CU's LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+  int tile;
+  {
+    const int T = gridDim.x, L = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = L & 7, i = L >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m_tile = tile / tiles_n;
+  const int n0 = (tile - m_tile * tiles_n) * BN, m0 = m_tile * BM;
+  const int bz = (p.splitk > 1) ? 0 : blockIdx.z;
+  const unsigned short* Wb = p.W + (size_t)bz * p.strideW;
+  const unsigned short* Ab = p.A + (size_t)bz * p.strideA;
+
+  const int nk_all = p.K / BK;
+  const int kt_begin = (p.splitk > 1) ? blockIdx.z * p.kt_per_slice : 0;
+  const int nk = (p.splitk > 1) ? min(p.kt_per_slice, nk_all - kt_begin) : nk_all;
+
+  // ---- DMA roles: instruction j of this wave covers tile rows 8*(wave + 4 j) .. +7; lane -> (row r = lane>>3, slot c);
+  // the 16-B slot of a row is XOR-swizzled on the SOURCE side (slot c of LDS row `row` holds global chunk c ^ ((row>>1)&7))
+  const int dr = lane >> 3, dc = lane & 7;
+  const unsigned short* wsrc[W_INST];
+#pragma unroll
+  for (int j = 0; j < W_INST; ++j) {
+    const int row = 8 * (wave + 4 * j) + dr;                     // tile-local row
+    const int n = min(n0 + row, p.N - 1);
+    wsrc[j] = Wb + (size_t)n * p.ldw + (size_t)kt_begin * BK + ((dc ^ ((row >> 1) & 7)) * 8);
+  }
+  const unsigned short* asrc[A_INST];                            // dense: row pointer at kt_begin; conv: image base + chunk
+  int ay[A_INST], ax[A_INST];
+#pragma unroll
+  for (int j = 0; j < A_INST; ++j) {
+    const int row = 8 * (wave + 4 * j) + dr;
+    const int m = min(m0 + row, p.M - 1);
+    const int ch = (dc ^ ((row >> 1) & 7)) * 8;
+    if (!CONV) {
+      asrc[j] = Ab + (size_t)m * p.lda + (size_t)kt_begin * BK + ch;
+      ay[j] = ax[j] = 0;
+    } else {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      ay[j] = yo * p.stride - 1;
+      ax[j] = xo * p.stride - 1;
+      asrc[j] = Ab + (size_t)b * p.Hin * p.Win * p.lda + ch;
+    }
+  }
+  int tap = 0, ci0 = 0;                                          // conv: tap / first input channel of the next K-tile to issue
+  if (CONV) { tap = (kt_begin * BK) / p.Cin; ci0 = kt_begin * BK - tap * p.Cin; }
+  int kt_issue = 0, st_issue = 0;                                // next K-tile to enqueue and the ring stage it goes to
+
+  auto issue_tile = [&]() {
+    unsigned short* Al = smem + st_issue * BUF;
+    unsigned short* Wl = Al + BM * RS;
+#pragma unroll
+    for (int j = 0; j < W_INST; ++j) ring_dma16(wsrc[j] + (size_t)kt_issue * BK, Wl + 8 * (wave + 4 * j) * RS);
+    if (!CONV) {
+#pragma unroll
+      for (int j = 0; j < A_INST; ++j) ring_dma16(asrc[j] + (size_t)kt_issue * BK, Al + 8 * (wave + 4 * j) * RS);
+    } else {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+#pragma unroll
+      for (int j = 0; j < A_INST; ++j) {
+        const int yi = ay[j] + ky, xi = ax[j] + kx;
+        const bool ok = (yi >= 0) & (yi < Hup) & (xi >= 0) & (xi < Wup);
+        const int ys = yi >> p.up, xs = xi >> p.up;
+        const unsigned short* src = ok ? asrc[j] + ((size_t)ys * p.Win + xs) * p.lda + ci0 : ring_zero_page + dc * 8;
+        ring_dma16(src, Al + 8 * (wave + 4 * j) * RS);
+      }
+      ci0 += BK;
+      if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
+    }
+    ++kt_issue;
+    st_issue = (st_issue + 1 == NS) ? 0 : st_issue + 1;
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int f_sw = (l31 >> 1) & 7;                      // read-side swizzle: fragment rows are (multiple of 32) + l31
+  auto compute = [&](int st) {
+    const unsigned short* Al = smem + st * BUF;
+    const unsigned short* Wl = Al + BM * RS;
+    const unsigned short* af_base = Al + (wm * WM + l31) * RS;
+    const unsigned short* wf_base = Wl + (wn * WN + l31) * RS;
+    u32x4 wf[2][TN], af[2][TM];                         // register double-buffered fragments
+    {
+      const int slot = (hi ^ f_sw) * 8;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[0][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[0][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BK / 16) {
+        const int slot = (((ks + 1) * 2 + hi) ^ f_sw) * 8;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[nxt][a] = *reinterpret_cast<const u32x4*>(wf_base + a * 32 * RS + slot);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) af[nxt][b] = *reinterpret_cast<const u32x4*>(af_base + b * 32 * RS + slot);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = Elem<DT>::mfma32(wf[cur][a], af[cur][b], acc[a][b]);
+    }
+  };
+
+  const int pre = min(NS - 1, nk);
+  for (int i = 0; i < pre; ++i) issue_tile();           // NS - 1 K-tiles in flight before the first wait
+  int st = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // K-tile kt has landed when at most the tiles enqueued behind it are outstanding (a wave's LDS-DMA retire in order) ...
+    ring_wait<PER_TILE, NS - 2>(kt_issue - kt - 1);
+    __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done with stage (kt - 1) % NS,
+    if (kt_issue < nk) issue_tile();                    // which K-tile kt + NS - 1 now refills
+    compute(st);
+    st = (st + 1 == NS) ? 0 : st + 1;
+  }
+  tile_epilogue<DT, BM, BN, WM, WN, LDS_BYTES>(p, acc, smem, m0, n0, bz, wm, wn, lane, wave);
+}
+
 // out = epi(sum over K-slices) for split-K launches: one thread per 8 consecutive columns of one row
 template <int DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) {
@@ -524,6 +698,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // vmcnt + raw s_barrier) was built and measured SLOWER than variant 2 on every shape but one (744 vs 846 TF at 8192^3,
 // 485 vs 644 at K=1280: a barrier per 8 MFMAs costs more than the deeper prefetch buys) and was removed; numbers in
 // profiles/r01_diag_B18_gemm_ring_vs_dma.log.
+std::atomic<long long> idf_stat_ring_launches{0};     // launches of the latency kernel (idf_get_stat)
 int g_big_mode = -2;
 inline int gemm_big_mode() {
   if (g_big_mode == -2) {
@@ -580,6 +755,63 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
   return idf_launch_status();
 }
 
+// Latency kernel (variant 3) dispatch: taken when the tile grid has at most g_ring_tiles tiles (0 = never).
+// IDF_GEMM_RING / idf_set_tuning(IDF_TUNE_GEMM_RING) set the threshold; default IDF_GEMM_RING_DEFAULT.
+#ifndef IDF_GEMM_RING_DEFAULT
+#define IDF_GEMM_RING_DEFAULT 0
+#endif
+int g_ring_tiles = -1;
+inline int gemm_ring_tiles() {
+  if (g_ring_tiles < 0) {
+    const char* e = getenv("IDF_GEMM_RING");
+    const int v = e ? atoi(e) : IDF_GEMM_RING_DEFAULT;
+    g_ring_tiles = v < 0 ? IDF_GEMM_RING_DEFAULT : v;
+  }
+  return g_ring_tiles;
+}
+
+// returns IDF_BIG_UNSUPPORTED when the launch is left to variants 1 / 2
+template <int DT, int BM, int BN, int WM, int WN, bool CONV, int NS>
+int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  const int nk = p.K / BK;
+  if (tiles > gemm_ring_tiles()) return IDF_BIG_UNSUPPORTED;
+  void (*kern)(const CoreParams) = gemm_kernel_ring<DT, BM, BN, WM, WN, CONV, NS>;
+  constexpr int cstage = 4 * WM * (WN + 4) * 4;
+  constexpr int kloop = NS * (BM + BN) * 64 * 2;
+  constexpr int smem = kloop > cstage ? kloop : cstage;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  CoreParams q = p;
+  q.splitk = 1; q.kt_per_slice = nk;
+  q.tail_m0 = 0; q.tail_rows = p.M;
+  // split-K towards one workgroup per CU (this kernel's occupancy), slices of >= 4 K-tiles: a slice then has its whole K
+  // range in flight at once and the launch is one trip to memory plus the reducer
+  const int slots = idf_num_cu();
+  if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles * 2 <= slots && nk >= 8) {
+    int want = slots / tiles;
+    if (want > nk / 4) want = nk / 4;
+    if (want > 64) want = 64;
+    while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > p.ws_bytes) --want;
+    if (want > 1) {
+      q.kt_per_slice = (nk + want - 1) / want;
+      q.splitk = (nk + q.kt_per_slice - 1) / q.kt_per_slice;
+    }
+  }
+  dim3 grid(tiles, 1, q.splitk > 1 ? q.splitk : batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, q);
+  ++idf_stat_ring_launches;
+  if (q.splitk > 1) {
+    const size_t n8 = (size_t)q.M * ((q.N + 7) / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, q);
+  }
+  return idf_launch_status();
+}
+
 template <int DT, bool CONV>
 int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullptr) {
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
@@ -620,7 +852,12 @@ int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullp
     if (!p.ln_stats_out) { q.ws = nullptr; q.ws_bytes = 0; }
   }
   // (64x64 tiles for short-K dense GEMMs were measured 6-20 % slower: profiles/r01_diag_B18_tile64_ab.log)
-  if (geglu || (q.N % 128 == 0) || q.N > 1024 || (use_wide && q.N > 128)) return launch_cfg<DT, 128, 128, 64, 64, CONV>(q, batch, s);
+  const bool t128 = geglu || (q.N % 128 == 0) || q.N > 1024 || (use_wide && q.N > 128);
+  if (gemm_ring_tiles() > 0) {                              // small grids: the latency kernel (variant 3), same tiles
+    const int rc = t128 ? launch_ring_cfg<DT, 128, 128, 64, 64, CONV, 4>(q, batch, s) : launch_ring_cfg<DT, 128, 64, 64, 32, CONV, 5>(q, batch, s);
+    if (rc != IDF_BIG_UNSUPPORTED) return rc;
+  }
+  if (t128) return launch_cfg<DT, 128, 128, 64, 64, CONV>(q, batch, s);
   return launch_cfg<DT, 128, 64, 64, 32, CONV>(q, batch, s);
 }
 
@@ -658,6 +895,16 @@ extern "C" int idf_set_tuning(int knob, int value) {
     g_big_mode = value;
     return prev;
   }
+  if (knob == IDF_TUNE_GEMM_RING) {
+    if (value < 0) return IDF_E_ARG;
+    const int prev = gemm_ring_tiles();
+    g_ring_tiles = value;
+    return prev;
+  }
+  if (knob == IDF_TUNE_GN_FUSED) {
+    if (value < 0 || value > 1) return IDF_E_ARG;
+    return idf_gn_fused_set(value);
+  }
   if (knob == IDF_TUNE_ATTN2) {
     if (value < 0 || value > 3) return IDF_E_ARG;
     return idf_attn2_set_mode(value);
@@ -668,6 +915,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
 extern "C" long long idf_get_stat(int stat) {
   if (stat == IDF_STAT_GEMM_BIG_LAUNCHES) return idf_stat_big_launches.load();
   if (stat == IDF_STAT_ATTN2_LAUNCHES) return idf_stat_attn2_launches.load();
+  if (stat == IDF_STAT_GEMM_RING_LAUNCHES) return idf_stat_ring_launches.load();
   return -1;
 }
 

@@ -50,6 +50,10 @@ MLP_FUSED = os.environ.get("IDF_MLP_FUSED", "1")
 if MLP_FUSED not in ("0", "1"):
     raise ValueError(f"IDF_MLP_FUSED={MLP_FUSED}: must be 0 or 1")
 MLP_FUSED = MLP_FUSED == "1" and GEGLU_PERIOD == 32
+# ... and only from IDF_MLP_MIN_M token rows up: the kernel's 128-row tiles run one per workgroup slot for ~110-175 us whatever
+# their number, so below a few hundred tiles (a 2-row forward has 64) the two small GEMMs are faster
+# (profiles/r04_mlp_small_m.log).
+MLP_MIN_M = int(os.environ.get("IDF_MLP_MIN_M", "32768"))
 # Paired forwards (classifier-free guidance: rows [n, 2n) carry the SAME latent and timestep as rows [0, n) and differ only in
 # their conditioning): everything in front of the first block that reads the conditioning -- first conv, first ResBlock,
 # GroupNorm, proj_in and the first 64 x 64 self-attention with its out-projection -- is computed ONCE for the n distinct
@@ -601,7 +605,7 @@ class UNetEngine:
         produced y: a GEGLU GEMM has 8-16 column tiles per row block, each of which would repeat the in-loop row sums --
         measured +15 % on those launches -- so here the separate 8-B-per-row pass is the cheaper form)."""
         ops = self.ops
-        if "w2p" in f and st is not None and LN_SELF_MODE != 2 and out_stats is None and ops.mlp_supported(M, C):
+        if "w2p" in f and st is not None and LN_SELF_MODE != 2 and out_stats is None and M >= MLP_MIN_M and ops.mlp_supported(M, C):
             return ops.mlp_geglu(y, st, f["w1"], f["cd"], f["w2p"], f["l2"].b, y, gate=gate)
         mid = ops.gemm(y, f["w1"], self.buf("st.ffmid", (M, 4 * C)), bias=f["b1"], geglu=True, geglu_period=GEGLU_PERIOD,
                        ln_row=(None if LN_SELF_MODE == 2 else st, f["c1"]))

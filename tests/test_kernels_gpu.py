@@ -307,6 +307,42 @@ def test_groupnorm_large_mean_over_std(ops, B, HW, C):
     assert err < 6e-3                                           # one bf16 rounding of outputs up to ~1.23 is 3.9e-3
 
 
+@pytest.fixture
+def gn_fused():
+    """Single-launch GroupNorm for small batches switched on (idf_set_tuning) for the duration of a test."""
+    from instancediffusion_amd import _lib
+    lib = _lib.load()
+    prev = lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 1)
+    yield
+    lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, prev)
+
+
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 64, True), (1, 4096, 320, True), (2, 64, 2560, True), (2, 4096, 320, True),
+                                         (3, 1024, 960, False), (1, 144, 1920, True), (2, 16, 128, False), (8, 1024, 640, True)])
+def test_groupnorm_single_launch(ops, ref, gn_fused, B, HW, C, silu):
+    """The small-batch form (statistics + device-wide rendezvous per sample + normalisation in one launch) against the same
+    reference and, repeated on the same workspace, bit for bit against itself: the rendezvous counters must reset."""
+    test_groupnorm(ops, ref, B, HW, C, silu)
+    x = to16(gen((B, HW, C), 56) * 0.8 - 0.2)
+    gm, bt = 1 + 0.1 * gen((C,), 57), 0.1 * gen((C,), 58)
+    want = ref.groupnorm(x.float(), torch.empty(B, HW, C), gm, bt, 1e-5, silu)
+    outs = [ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, silu) for _ in range(20)]
+    torch.cuda.synchronize()
+    assert relmax(outs[0], want) < BF16_TOL
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    # ... and the two-launch form gives the same statistics up to their fp32 merge order
+    from instancediffusion_amd import _lib
+    _lib.load().idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 0)
+    two = ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, silu)
+    torch.cuda.synchronize()
+    _lib.load().idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 1)
+    assert relmax(outs[0], two) < BF16_TOL
+
+
+def test_groupnorm_single_launch_large_mean(ops, gn_fused):
+    test_groupnorm_large_mean_over_std(ops, 2, 1000, 640)
+
+
 @pytest.mark.parametrize("M,C", [(4096, 320), (1000, 640), (77, 1280), (5, 64), (184, 128)])
 def test_layernorm(ops, ref, M, C):
     x = to16(gen((M, C), 53) * 2 + 0.3)
@@ -636,6 +672,101 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     torch.cuda.synchronize()
     assert lib.idf_get_stat(0) - start == 4 and bool((o5 == o5[:1]).all())
     lib.idf_set_tuning(0, prev_mode)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the latency kernel of the small-batch launches (gemm_kernel_ring, gemm_conv.hip), forced through idf_set_tuning
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture
+def ring():
+    """Keep the persistent kernel out and send EVERY GEMM / conv launch to the latency kernel (threshold = any tile count);
+    yields a callable returning how many launches it served since the fixture started."""
+    from instancediffusion_amd import _lib
+    lib = _lib.load()
+    prev_big = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_BIG, 0)
+    prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 1 << 30)
+    start = lib.idf_get_stat(_lib.IDF_STAT_GEMM_RING_LAUNCHES)
+    yield lambda: lib.idf_get_stat(_lib.IDF_STAT_GEMM_RING_LAUNCHES) - start
+    lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, prev)
+    lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_BIG, prev_big)
+
+
+# shapes of a 2-row forward (K = 320: the whole K range in flight; split-K at the 16x16 / 8x8 levels), fewer K-tiles than ring
+# stages (K = 64 / 128 / 192), ragged M and N, a 2-row time-embedding GEMM
+@pytest.mark.parametrize("M,N,K", [(8192, 320, 320), (2048, 640, 640), (512, 1280, 1280), (128, 1280, 5120), (1000, 960, 192),
+                                   (128, 128, 64), (77, 64, 768), (300, 72, 128), (2, 20160, 1280), (4096, 1280, 2560)])
+def test_gemm_ring_bias(ops, ref, ring, M, N, K):
+    test_gemm_bias(ops, ref, M, N, K)
+    assert ring() == 1
+
+
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_gemm_ring_epilogues(ops, ref, ring, act):
+    test_gemm_epilogues(ops, act)
+    test_gemm_geglu(ops, ref)
+    test_gemm_batched_transposed_v(ops)
+    test_gemm_f32_out_and_strided_out(ops)
+    assert ring() >= 6
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(300, 640, 320, "row"), (4096, 1280, 640, "row"), (200, 2560, 320, "geglu"),
+                                        (320, 200, 320, "col"), (640, 4096, 640, "col")])
+def test_gemm_ring_layernorm_folded(ops, ring, M, N, K, mode):
+    test_gemm_layernorm_folded(ops, M, N, K, mode)
+    assert ring() >= 1
+
+
+@pytest.mark.parametrize("M,C,stats", [(4096, 1280, "none"), (200, 320, "given"), (1000, 320, "self")])
+def test_gemm_ring_geglu_period32(ops, ring, M, C, stats):
+    test_gemm_geglu_period32(ops, M, C, stats)
+    assert ring() >= 2
+
+
+@pytest.mark.parametrize("M,C,own", [(8192 + 16, 320, True), (2048, 640, False), (1000, 320, True)])
+def test_gemm_ring_fused_qkv_fallback(ops, ring, M, C, own):
+    test_gemm_fused_qkv_transposed_v(ops, M, C, own)
+    assert ring() >= 2
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [
+    (1, 16, 16, 64, 64, 1, 0), (2, 8, 8, 320, 640, 1, 0), (2, 16, 16, 128, 128, 2, 0), (1, 8, 8, 128, 128, 1, 1),
+    (1, 12, 12, 192, 320, 1, 0), (1, 7, 9, 64, 64, 2, 0), (2, 8, 8, 1280, 1280, 1, 0), (2, 16, 16, 1280, 1280, 1, 1)])
+def test_conv3x3_ring(ops, ref, ring, B, H, W, Cin, Cout, stride, up):
+    test_conv3x3(ops, ref, B, H, W, Cin, Cout, stride, up)
+    assert ring() == 1
+
+
+def test_gemm_ring_matches_small_kernels_bitwise_on_exact_data(ops, ring):
+    """Integer-valued operands: every partial sum is exact in fp32, so the latency kernel (its own split-K rule included) and the
+    K-loop variants 1 / 2 it replaces must agree bit for bit -- dense with a residual, split-K dense, and a split-K conv."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import pack_conv3x3
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(71)
+
+    def both(fn):
+        o1 = fn()
+        torch.cuda.synchronize()
+        n1 = ring()
+        lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 0)
+        o2 = fn()
+        torch.cuda.synchronize()
+        lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 1 << 30)
+        assert ring() == n1, "the second run must not touch the latency kernel"
+        return o1, o2
+
+    for M, N, K in [(8192, 320, 320), (512, 1280, 1280), (130, 1280, 5120)]:
+        a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+        w = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+        r = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16)
+        o1, o2 = both(lambda: ops.gemm(dev(a), dev(w), ops.empty((M, N)), res=dev(r)))
+        assert torch.equal(o1, o2)
+        assert torch.equal(o1.float().cpu(), (a.float() @ w.float().t() + r.float()).to(torch.bfloat16).float())
+    B, H, Cin, Cout = 2, 8, 1280, 1280
+    x = torch.randint(-2, 3, (B, H, H, Cin), generator=g).to(torch.bfloat16)
+    wp = pack_conv3x3(torch.randint(-2, 3, (Cout, Cin, 3, 3), generator=g).float()).to(torch.bfloat16)
+    o1, o2 = both(lambda: ops.conv3x3(dev(x), dev(wp), ops.empty((B, H, H, Cout))))
+    assert torch.equal(o1, o2)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -982,12 +1113,15 @@ def test_gemm_fused_qkv_transposed_v(ops, M, C, own):
     if own:
         xf = x.float()
         assert float((st[:, 0].cpu() - xf.mean(-1)).abs().max()) < 1e-4
-    # exact data, no LayerNorm: the transposed tiles must equal the plain product bit for bit
+    # exact data, identity LayerNorm fold ((mu, rstd) = (0, 1), c = d = 0: the epilogue the fused form requires, arithmetic-free):
+    # the transposed tiles must equal the plain product bit for bit
     g = torch.Generator().manual_seed(106)
     ai = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
     wi = torch.randint(-3, 4, (3 * C, K), generator=g).to(torch.bfloat16)
     qk2, vt2 = ops.empty((M, 2 * C)), ops.empty((C, M))
-    ops.gemm(dev(ai), dev(wi), qk2, vt_out=vt2)
+    st0 = torch.tensor([0.0, 1.0]).repeat(M, 1).cuda()
+    zero = torch.zeros(3 * C, device="cuda")
+    ops.gemm(dev(ai), dev(wi), qk2, bias=zero, ln_row=(st0, zero), vt_out=vt2)
     torch.cuda.synchronize()
     exact = (ai.float() @ wi.float().t()).to(torch.bfloat16)
     assert torch.equal(qk2.cpu(), exact[:, :2 * C]) and torch.equal(vt2.cpu(), exact[:, 2 * C:].t())
@@ -1002,15 +1136,22 @@ def test_gemm_fused_qkv_f16_and_argument_checks():
     ai = torch.randint(-3, 4, (M, C), generator=g).half()
     wi = torch.randint(-3, 4, (3 * C, C), generator=g).half()
     qk, vt = o16.empty((M, 2 * C)), o16.empty((C, M))
-    o16.gemm(dev(ai), dev(wi), qk, vt_out=vt)
+    st0 = torch.tensor([0.0, 1.0]).repeat(M, 1).cuda()           # identity LayerNorm fold: (mu, rstd) = (0, 1), c = d = 0
+    zero = torch.zeros(3 * C, device="cuda")
+    o16.gemm(dev(ai), dev(wi), qk, bias=zero, ln_row=(st0, zero), vt_out=vt)
     torch.cuda.synchronize()
     exact = (ai.float() @ wi.float().t()).half()
     assert torch.equal(qk.cpu(), exact[:, :2 * C]) and torch.equal(vt.cpu(), exact[:, 2 * C:].t())
-    # epilogues the transposed tiles do not implement are refused, not silently dropped
+    # epilogues the transposed tiles do not implement are refused, not silently dropped -- and so is a call without the
+    # LayerNorm fold (its two-GEMM form could not carry the transposed columns' bias; include/idf.h)
     with pytest.raises(_lib.IdfError):
-        o16.gemm(dev(ai), dev(wi), qk, vt_out=vt, act="silu")
+        o16.gemm(dev(ai), dev(wi), qk, bias=zero, ln_row=(st0, zero), vt_out=vt, act="silu")
     with pytest.raises(_lib.IdfError):
-        o16.gemm(dev(ai), dev(wi), qk, vt_out=vt, res=qk)
+        o16.gemm(dev(ai), dev(wi), qk, bias=zero, ln_row=(st0, zero), vt_out=vt, res=qk)
+    with pytest.raises(_lib.IdfError):
+        o16.gemm(dev(ai), dev(wi), qk, vt_out=vt)
+    with pytest.raises(_lib.IdfError):
+        o16.gemm(dev(ai), dev(wi), qk, bias=zero, vt_out=vt)
 
 
 @pytest.mark.parametrize("M,N,K,offset", [(65536, 320, 320, 0.0), (65536 + 48, 320, 320, 40.0), (32768, 640, 640, 0.0),

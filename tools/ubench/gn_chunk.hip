@@ -25,7 +25,8 @@ int main(int argc, char** argv) {
     std::vector<float> o(4096, 1.0f), z(4096, 0.1f);
     hipMemcpy(g, o.data(), 4096 * 4, hipMemcpyHostToDevice); hipMemcpy(b, z.data(), 4096 * 4, hipMemcpyHostToDevice);
   }
-  hipMalloc(&ws, (size_t)idf_groupnorm_ws_floats(128, 4096) * 4);
+  hipMalloc(&ws, (size_t)idf_groupnorm_ws_floats(128, 4096) * 4 + (1 << 20));
+  hipMemset(ws, 0, (size_t)idf_groupnorm_ws_floats(128, 4096) * 4 + (1 << 20));       // idf_groupnorm's contract (include/idf.h)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (const S& sh : shapes) {
     const size_t n = (size_t)sh.B * sh.HW * sh.C;

@@ -142,7 +142,9 @@ int main(int argc, char** argv) {
     }
     // ---- timing
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int Mt : {262144, 524288}) {
+    // (8192 ... 65536 = 2 ... 16-row forwards: where the fused kernel's 128-row tiles stop filling the chip -- the engine's
+    // row threshold comes from these lines; the two-GEMM side follows the library's IDF_GEMM_RING default)
+    for (int Mt : {8192, 16384, 32768, 49152, 65536, 262144, 524288}) {
       std::vector<double> tf, tg;
       for (int rd = 0; rd < 3; ++rd)
         for (int which = 0; which < 2; ++which) {

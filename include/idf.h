@@ -76,9 +76,12 @@ const char* idf_build_info(void);
  *   IDF_TUNE_GN_FUSED (round 4): 1 = idf_groupnorm runs small batches (B <= 8, <= 256 workgroups) as ONE launch (statistics,
  *   device-wide rendezvous per sample, normalisation); 0 = always the two launches.  Initial value: env IDF_GN_FUSED or the
  *   library default.
+ *   IDF_TUNE_BIG_MIN_EFF (round 4): occupancy bar of IDF_TUNE_GEMM_BIG's automatic rule in per cent (1..100): the persistent
+ *   kernel takes a launch whose tile grid fills at least this share of the workgroup slots of its last round.  Initial value:
+ *   env IDF_BIG_MIN_EFF or the library default.
  * (ABI 2 also exposed the kernel variants that were measured slower -- GEMM geometries 1..6, attention modes 1..14; they
  * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.) */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_GN_FUSED = 3 };
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_GN_FUSED = 3, IDF_TUNE_BIG_MIN_EFF = 4 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2 };

@@ -962,6 +962,23 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
 std::atomic<long long> idf_stat_big_launches{0};
 int idf_num_cu() { return num_cu(); }
 
+// Occupancy bar of the automatic rule: the persistent kernel takes a launch when its tile grid fills at least this share of the
+// workgroup slots of its last round (idf_launch_big).  set >= 0: new value, returns the previous one; set < 0: query.
+#ifndef IDF_BIG_MIN_EFF_DEFAULT
+#define IDF_BIG_MIN_EFF_DEFAULT 50
+#endif
+int idf_big_min_eff_pct(int set) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("IDF_BIG_MIN_EFF");
+    const int x = e ? atoi(e) : IDF_BIG_MIN_EFF_DEFAULT;
+    v = (x < 1 || x > 100) ? IDF_BIG_MIN_EFF_DEFAULT : x;
+  }
+  const int prev = v;
+  if (set >= 0) v = set;
+  return prev;
+}
+
 // Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
 int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out, int* parts_out,
                    int* tail_m0_out) {
@@ -1016,7 +1033,7 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
     const long long items = tiles * splitk;
     const long long rounds = (items + slots - 1) / slots;
     const double eff = (double)items / (double)(rounds * slots);
-    if (eff < 0.80) {
+    if (eff * 100.0 < (double)idf_big_min_eff_pct(-1)) {
       // Hybrid (round 3): at least one full round of whole tiles, and the tiles beyond the last full round (whole m-tiles
       // only, so that the tail is a row range) cut into S | K-tiles slices, one per workgroup of the last round.
       const int tiles_n = p.N / bn;

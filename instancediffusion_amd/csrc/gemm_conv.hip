@@ -758,7 +758,7 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
 // Latency kernel (variant 3) dispatch: taken when the tile grid has at most g_ring_tiles tiles (0 = never).
 // IDF_GEMM_RING / idf_set_tuning(IDF_TUNE_GEMM_RING) set the threshold; default IDF_GEMM_RING_DEFAULT.
 #ifndef IDF_GEMM_RING_DEFAULT
-#define IDF_GEMM_RING_DEFAULT 0
+#define IDF_GEMM_RING_DEFAULT 256
 #endif
 int g_ring_tiles = -1;
 inline int gemm_ring_tiles() {
@@ -776,6 +776,10 @@ int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   const int nk = p.K / BK;
   if (tiles > gemm_ring_tiles()) return IDF_BIG_UNSUPPORTED;
+  const int slots = idf_num_cu();
+  // a grid of 129 ... 191 tiles with a long K: variants 1 / 2 cut it into K-slices for their two workgroups per CU, this
+  // kernel (one per CU) cannot -- throughput, not latency, decides there (3x3 conv 16^2 -> 32^2 at 2 rows: 105 vs 141 us)
+  if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles * 2 > slots && tiles < 192 && nk >= 8) return IDF_BIG_UNSUPPORTED;
   void (*kern)(const CoreParams) = gemm_kernel_ring<DT, BM, BN, WM, WN, CONV, NS>;
   constexpr int cstage = 4 * WM * (WN + 4) * 4;
   constexpr int kloop = NS * (BM + BN) * 64 * 2;
@@ -791,7 +795,6 @@ int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
   q.tail_m0 = 0; q.tail_rows = p.M;
   // split-K towards one workgroup per CU (this kernel's occupancy), slices of >= 4 K-tiles: a slice then has its whole K
   // range in flight at once and the launch is one trip to memory plus the reducer
-  const int slots = idf_num_cu();
   if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles * 2 <= slots && nk >= 8) {
     int want = slots / tiles;
     if (want > nk / 4) want = nk / 4;
@@ -825,7 +828,14 @@ int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullp
   // K-loop variant 4 (gemm_big.hip): persistent 256 x {320,256} tiles.  IDF_GEMM_BIG=0 off, 1 auto (shape + tile
   // quantisation heuristic), 2 forced whenever the shape qualifies.
   const int big = gemm_big_mode();
-  if (big > 0 && batch == 1) {
+  // Order (round 4, profiles/r04_dispatch_variants_2_16_64_128_rows.log): a grid of at most 128 small tiles goes to the latency
+  // kernel BEFORE the persistent kernel is asked (at 2 rows it beats the persistent kernel's split-K form on every conv and
+  // GEMM of the 32^2 ... 8^2 levels); larger grids ask the persistent kernel first (its occupancy bar is 50 %), then the latency
+  // kernel up to its threshold, then variants 1 / 2.  Forcing the persistent kernel (mode 2) keeps it first.
+  const bool t128p = geglu || (p.N % 128 == 0) || p.N > 1024 || (use_wide && p.N > 128);
+  const long long tiles_small = (long long)((p.N + (t128p ? 127 : 63)) / (t128p ? 128 : 64)) * ((p.M + 127) / 128);
+  const bool ring_first = big != 2 && gemm_ring_tiles() > 0 && tiles_small <= 128 && tiles_small <= gemm_ring_tiles();
+  if (big > 0 && batch == 1 && !ring_first) {
     int splitk = 1, tail_m0 = 0;
     // mode 3 = automatic + hybrid tail split (the dispatcher only cuts a tail when it is given somewhere to report it)
     const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out, big == 3 ? &tail_m0 : nullptr);
@@ -900,6 +910,10 @@ extern "C" int idf_set_tuning(int knob, int value) {
     const int prev = gemm_ring_tiles();
     g_ring_tiles = value;
     return prev;
+  }
+  if (knob == IDF_TUNE_BIG_MIN_EFF) {
+    if (value < 1 || value > 100) return IDF_E_ARG;
+    return idf_big_min_eff_pct(value);
   }
   if (knob == IDF_TUNE_GN_FUSED) {
     if (value < 0 || value > 1) return IDF_E_ARG;

@@ -137,6 +137,7 @@ extern std::atomic<long long> idf_stat_big_launches;     // process-global launc
 // offered and the launch was an unsplit dense GEMM), the number of slots per row.
 int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out,
                    int* parts_out = nullptr, int* tail_m0_out = nullptr);
+int idf_big_min_eff_pct(int set);                        // automatic rule's occupancy bar in per cent (set < 0: query)
 int idf_num_cu();                                        // CUs of the current device (cached)
 // (mu, rstd) per row from `parts` equal-count (mean, M2) slots per row (fixed merge order): out_stats[m] = f32x2
 int idf_stats_finalize(const float* stat_parts, int parts, int cols_per_part, float* out_stats, int M, float eps, hipStream_t s);

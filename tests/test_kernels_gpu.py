@@ -615,6 +615,9 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     from instancediffusion_amd.engine import pack_conv3x3
     lib = _lib.load()
     prev_mode = lib.idf_set_tuning(0, 3)                                 # automatic dispatch + hybrid tail split (opt-in)
+    # (the hybrid form serves grids BELOW the automatic rule's occupancy bar; the shapes here sit at 56 %, between the
+    # round-3 bar the mechanism was built under and the round-4 default of 50 %)
+    prev_bar = lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 80)
     start = lib.idf_get_stat(0)
     # 18 rows of the 64^2 level: M = 73728 -> 288 tiles of 256 x 320; K = 1280 (20 K-tiles -> 5 slices of 4)
     M, N, K = 18 * 4096, 320, 1280
@@ -672,6 +675,7 @@ def test_big_kernel_hybrid_tail_split(ops, ref):
     torch.cuda.synchronize()
     assert lib.idf_get_stat(0) - start == 4 and bool((o5 == o5[:1]).all())
     lib.idf_set_tuning(0, prev_mode)
+    lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, prev_bar)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -694,10 +698,17 @@ def ring():
 # shapes of a 2-row forward (K = 320: the whole K range in flight; split-K at the 16x16 / 8x8 levels), fewer K-tiles than ring
 # stages (K = 64 / 128 / 192), ragged M and N, a 2-row time-embedding GEMM
 @pytest.mark.parametrize("M,N,K", [(8192, 320, 320), (2048, 640, 640), (512, 1280, 1280), (128, 1280, 5120), (1000, 960, 192),
-                                   (128, 128, 64), (77, 64, 768), (300, 72, 128), (2, 20160, 1280), (4096, 1280, 2560)])
+                                   (128, 128, 64), (77, 64, 768), (300, 72, 128), (2, 10240, 1280), (4096, 1280, 2560)])
 def test_gemm_ring_bias(ops, ref, ring, M, N, K):
     test_gemm_bias(ops, ref, M, N, K)
     assert ring() == 1
+
+
+def test_gemm_ring_declines_what_only_split_k_fills(ops, ref, ring):
+    """129 ... 191 tiles with a long K (the 2-row time-embedding GEMM: 158 tiles, 20 K-tiles): variants 1 / 2 split K for their
+    two workgroups per CU, the one-per-CU latency kernel cannot and leaves the launch to them."""
+    test_gemm_bias(ops, ref, 2, 20160, 1280)
+    assert ring() == 0
 
 
 @pytest.mark.parametrize("act", [None, "gelu"])

@@ -31,17 +31,40 @@ __global__ void diff_kernel(const unsigned short* a, const unsigned short* b, si
 
 struct Shape { const char* name; int count; bool conv; int M, N, K, epi; int H, Cin, stride, up; };
 
+// GPU time per call of `fn(stream)`: `reps` calls captured into ONE hipGraph (what the engine replays), launched three times,
+// the third timed -- eager back-to-back launches of 10-us kernels measure the host's launch rate instead (first version of
+// this harness: profiles/r04_small_family_eager_host_bound.log).
+template <class F> static double graph_us(F&& fn, int reps, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  hipGraph_t g; hipGraphExec_t ge;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
+  for (int i = 0; i < reps; ++i) fn(st);
+  if (hipStreamEndCapture(st, &g) != hipSuccess) return -1;
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) return -1;
+  hipGraphLaunch(ge, st); hipGraphLaunch(ge, st);
+  hipEventRecord(e0, st);
+  hipGraphLaunch(ge, st);
+  hipEventRecord(e1, st);
+  if (hipStreamSynchronize(st) != hipSuccess) return -2;
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return ms * 1e3 / reps;
+}
+
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
   const int rounds = argc > 2 ? atoi(argv[2]) : 3;
-  const size_t max_elems = (size_t)16 * 4096 * 2560;            // largest operand / output (16 rows, GEGLU output at 64^2)
+  const int RMAX = argc > 3 ? atoi(argv[3]) : 16;
+  const size_t max_elems = (size_t)RMAX * 4096 * 2560;          // largest operand / output (GEGLU output at 64^2)
+  // 1 GiB of weights: every captured launch of a shape reads ANOTHER weight matrix (as the layers of a forward do -- 2.5 GB of
+  // weights stream from HBM once per forward; re-launching one layer would serve them from L2 / the 256 MB Infinity Cache)
+  const size_t W_ELEMS = (size_t)512 << 20;
   unsigned short *a, *w, *o0, *o1, *r;
   float *bias, *ws, *stats, *lnc;
   unsigned long long* mism; float *maxabs, *maxref;
   hipMalloc(&mism, 8); hipMalloc(&maxabs, 4); hipMalloc(&maxref, 4);
   hipMalloc(&a, max_elems * 2); hipMalloc(&o0, max_elems * 2); hipMalloc(&o1, max_elems * 2); hipMalloc(&r, max_elems * 2);
-  hipMalloc(&w, (size_t)64 << 20 << 1); hipMalloc(&bias, 32768 * 4); hipMalloc(&lnc, 32768 * 4); hipMalloc(&ws, (size_t)256 << 20);
-  hipMalloc(&stats, (size_t)16 * 4096 * 2 * 4);
+  hipMalloc(&w, W_ELEMS * 2); hipMalloc(&bias, 32768 * 4); hipMalloc(&lnc, 32768 * 4); hipMalloc(&ws, (size_t)256 << 20);
+  hipMalloc(&stats, (size_t)RMAX * 4096 * 2 * 4);
   {
     std::vector<unsigned short> h((size_t)16 << 20);
     unsigned x = 12345u;
@@ -52,21 +75,23 @@ int main(int argc, char** argv) {
       hipMemcpy(a + off, h.data(), n * 2, hipMemcpyHostToDevice);
       hipMemcpy(r + off, h.data() + 7, (n - 7) * 2, hipMemcpyHostToDevice);
     }
-    for (size_t off = 0; off < ((size_t)64 << 20); off += h.size()) hipMemcpy(w + off, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    for (size_t off = 0; off < W_ELEMS; off += h.size()) hipMemcpy(w + off, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     std::vector<float> hb(32768);
     for (auto& v : hb) { x = x * 1664525u + 1013904223u; v = (((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.5f; }
     hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
     for (auto& v : hb) { x = x * 1664525u + 1013904223u; v = (((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.1f; }
     hipMemcpy(lnc, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
-    std::vector<float> hs((size_t)16 * 4096 * 2);
+    std::vector<float> hs((size_t)RMAX * 4096 * 2);
     for (size_t i = 0; i < hs.size(); i += 2) { x = x * 1664525u + 1013904223u; hs[i] = (((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.02f; hs[i + 1] = 0.9f + (x & 255) / 1024.0f; }
     hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
   }
   const int B_ = IDF_EPI_BIAS, BR = IDF_EPI_BIAS | IDF_EPI_RES, GLU = IDF_EPI_BIAS | IDF_EPI_GEGLU | IDF_EPI_GEGLU_P32;
   const int LNB = IDF_EPI_BIAS | IDF_EPI_LN_ROW;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipStream_t st; hipStreamCreate(&st);
   const int thresholds[] = {128, 256, 512, 1024, 1 << 30};
-  for (int R : {2, 16}) {
+  for (int R : {2, 16, 64, 128}) {
+    if (R > RMAX) break;
     std::vector<Shape> shapes;
     const int HW[4] = {4096, 1024, 256, 64}, CH[4] = {320, 640, 1280, 1280}, HH[4] = {64, 32, 16, 8};
     // transformer layers per level (down + up): 64^2: 2 + 3, 32^2: 2 + 3, 16^2: 2 + 3, 8^2: the middle block's one
@@ -100,7 +125,7 @@ int main(int argc, char** argv) {
     shapes.push_back({"time-emb 22 x emb_layers", 1, false, R, 20160, 1280, B_, 0, 0, 1, 0});
 
     printf("==== %d-row forward\n", R);
-    double tot0 = 0, tot1 = 0, tot_thr[5] = {0, 0, 0, 0, 0};
+    double tot0 = 0, tot1 = 0, tot_thr[5] = {0, 0, 0, 0, 0}, totv[4] = {0, 0, 0, 0}, totbest = 0;
     for (const Shape& sh : shapes) {
       idf_gemm_args g{}; idf_conv3x3_args c{};
       int M = sh.M, K = sh.K, n_out = (sh.epi & IDF_EPI_GEGLU) ? sh.N / 2 : sh.N;
@@ -115,38 +140,47 @@ int main(int argc, char** argv) {
         g.batch = 1; g.epi = sh.epi; g.dtype = IDF_BF16; g.ws = ws; g.ws_bytes = (long long)256 << 20;
         if (sh.epi & IDF_EPI_LN_ROW) { g.ln_stats = stats; g.ln_c = lnc; }
       }
-      auto run = [&](unsigned short* out) { if (sh.conv) { c.out = out; return idf_conv3x3(&c, nullptr); } g.out = out; return idf_gemm(&g, nullptr); };
-      std::vector<double> t[2];
+      const size_t w_elems = (((size_t)sh.N * K + 4095) / 4096) * 4096, w_slots = W_ELEMS / w_elems;
+      size_t w_i = 0;
+      auto run = [&](unsigned short* out, hipStream_t s_ = nullptr) {
+        const unsigned short* wp = w + (w_i++ % w_slots) * w_elems;
+        if (sh.conv) { c.W = wp; c.out = out; return idf_conv3x3(&c, s_); }
+        g.W = wp; g.out = out; return idf_gemm(&g, s_);
+      };
+      // variants: 0 = round-3 dispatch (K-loop variants 1 / 2 below the persistent kernel's 80 % occupancy bar), 1 = + latency
+      // kernel for grids of <= 256 tiles, 2 = persistent kernel FORCED, 3 = latency kernel + occupancy bar at 50 %
+      std::vector<double> t[4];
       long long ring_launches = 0;
       int rc0 = 0;
       for (int rd = 0; rd < rounds && !rc0; ++rd)
-        for (int v = 0; v < 2; ++v) {
-          idf_set_tuning(IDF_TUNE_GEMM_RING, v ? (1 << 30) : 0);
-          unsigned short* out = v ? o1 : o0;
+        for (int v = 0; v < 4; ++v) {
+          idf_set_tuning(IDF_TUNE_GEMM_RING, (v == 1 || v == 3) ? 256 : 0);
+          idf_set_tuning(IDF_TUNE_GEMM_BIG, v == 2 ? 2 : 1);
+          idf_set_tuning(IDF_TUNE_BIG_MIN_EFF, v == 3 ? 50 : 80);
+          unsigned short* out = v == 1 ? o1 : o0;
           if (rd == 0) hipMemsetAsync(out, 0xff, (size_t)M * n_out * 2, 0);
           const long long before = idf_get_stat(IDF_STAT_GEMM_RING_LAUNCHES);
+          w_i = 0;                                           // every variant leaves the product with the SAME weights in `out` ...
           int rc = run(out);                                 // warm
-          if (rc) { printf("%-30s rc %d (ring %d)\n", sh.name, rc, v); rc0 = rc; break; }
-          if (v) ring_launches = idf_get_stat(IDF_STAT_GEMM_RING_LAUNCHES) - before;
-          hipEventRecord(e0, 0);
-          for (int i = 0; i < reps; ++i) run(out);
-          hipEventRecord(e1, 0);
+          if (rc) { printf("%-30s rc %d (variant %d)\n", sh.name, rc, v); rc0 = rc; break; }
+          if (v == 1) ring_launches = idf_get_stat(IDF_STAT_GEMM_RING_LAUNCHES) - before;
           if (hipDeviceSynchronize() != hipSuccess) { printf("%-30s device error: %s\n", sh.name, hipGetErrorString(hipGetLastError())); return 1; }
-          float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-          t[v].push_back(ms * 1e3 / reps);
+          const double us = graph_us([&](hipStream_t s_) { run(out, s_); }, reps, st, e0, e1);
+          if (us < 0) { printf("%-30s graph capture / replay failed (%g)\n", sh.name, us); return 1; }
+          t[v].push_back(us);
         }
+      idf_set_tuning(IDF_TUNE_GEMM_BIG, 1); idf_set_tuning(IDF_TUNE_BIG_MIN_EFF, 80);
       if (rc0) continue;
-      hipMemset(mism, 0, 8); hipMemset(maxabs, 0, 4); hipMemset(maxref, 0, 4);
-      hipLaunchKernelGGL(diff_kernel, dim3(256), dim3(256), 0, 0, o1, o0, (size_t)M * n_out, mism, maxabs, maxref);
-      unsigned long long nm_ = 0; float ma = 0, mr = 0;
-      hipMemcpy(&nm_, mism, 8, hipMemcpyDeviceToHost); hipMemcpy(&ma, maxabs, 4, hipMemcpyDeviceToHost); hipMemcpy(&mr, maxref, 4, hipMemcpyDeviceToHost);
-      std::sort(t[0].begin(), t[0].end()); std::sort(t[1].begin(), t[1].end());
-      const double u0 = t[0][t[0].size() / 2], u1 = t[1][t[1].size() / 2];
+      double u[4];
+      for (int v = 0; v < 4; ++v) { std::sort(t[v].begin(), t[v].end()); u[v] = t[v][t[v].size() / 2]; }
+      const double u0 = u[0], u1 = u[1];
       const bool t128 = (sh.epi & IDF_EPI_GEGLU) || sh.N % 128 == 0 || sh.N > 1024 || (sh.conv && sh.N > 128);
       const long tiles = (long)((sh.N + (t128 ? 127 : 63)) / (t128 ? 128 : 64)) * ((M + 127) / 128);
-      printf("%-30s x%-3d M%-6d N%-5d K%-5d tiles %5ld  base %7.1f us  ring %7.1f us  %+6.1f %%  ring launches %lld  differing %llu of %zu, max |d| %.3g (max |ref| %.3g)\n",
-             sh.name, sh.count, M, sh.N, K, tiles, u0, u1, (u0 / u1 - 1.0) * 100.0, ring_launches, nm_, (size_t)M * n_out, ma, mr);
+      printf("%-30s x%-3d M%-6d N%-5d K%-5d tiles %5ld  r3 %7.1f  +ring256 %7.1f (%lld)  big-forced %7.1f  ring256+eff50 %7.1f us  %+6.1f %%\n",
+             sh.name, sh.count, M, sh.N, K, tiles, u[0], u[1], ring_launches, u[2], u[3], (u[0] / u[3] - 1.0) * 100.0);
       fflush(stdout);
+      for (int v = 0; v < 4; ++v) totv[v] += sh.count * u[v];
+      totbest += sh.count * std::min(std::min(u[0], u[1]), std::min(u[2], u[3]));
       tot0 += sh.count * u0; tot1 += sh.count * u1;
       for (int i = 0; i < 5; ++i) tot_thr[i] += sh.count * (tiles <= thresholds[i] ? u1 : u0);
     }
@@ -155,30 +189,38 @@ int main(int argc, char** argv) {
                            {256, 1280, 11}, {256, 2560, 2}, {256, 640, 1}, {256, 1920, 1}, {64, 1280, 12}, {64, 2560, 3}};
       const size_t gws_bytes = (size_t)idf_groupnorm_ws_floats(R, 4096) * 4 + (1 << 20);
       float* gws; hipMalloc(&gws, gws_bytes); hipMemset(gws, 0, gws_bytes);      // zero-filled: idf_groupnorm's contract
-      double tot = 0;
+      double tot[2] = {0, 0};
+      unsigned short* og[2] = {o0, o1};
       for (auto& s3 : gn) {
-        std::vector<double> tt;
-        for (int rd = 0; rd < rounds; ++rd) {
-          int rc = idf_groupnorm(a, o0, bias, lnc, gws, R, s3[0], s3[1], 1e-5f, 1, IDF_BF16, nullptr);
-          if (rc) { printf("groupnorm rc %d\n", rc); break; }
-          hipEventRecord(e0, 0);
-          for (int i = 0; i < reps; ++i) idf_groupnorm(a, o0, bias, lnc, gws, R, s3[0], s3[1], 1e-5f, 1, IDF_BF16, nullptr);
-          hipEventRecord(e1, 0);
-          hipDeviceSynchronize();
-          float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-          tt.push_back(ms * 1e3 / reps);
-        }
-        if (tt.empty()) continue;
-        std::sort(tt.begin(), tt.end());
-        printf("groupnorm (%d, %d, %d) x%-2d %7.1f us\n", R, s3[0], s3[1], s3[2], tt[tt.size() / 2]);
-        tot += s3[2] * tt[tt.size() / 2];
+        std::vector<double> tt[2];
+        for (int rd = 0; rd < rounds; ++rd)
+          for (int v = 0; v < 2; ++v) {                         // 0 = two launches, 1 = single launch (statistics + rendezvous + apply)
+            idf_set_tuning(IDF_TUNE_GN_FUSED, v);
+            int rc = idf_groupnorm(a, og[v], bias, lnc, gws, R, s3[0], s3[1], 1e-5f, 1, IDF_BF16, nullptr);
+            if (rc) { printf("groupnorm rc %d\n", rc); break; }
+            if (hipDeviceSynchronize() != hipSuccess) { printf("groupnorm device error\n"); return 1; }
+            const double us = graph_us([&](hipStream_t s_) { idf_groupnorm(a, og[v], bias, lnc, gws, R, s3[0], s3[1], 1e-5f, 1, IDF_BF16, s_); }, reps, st, e0, e1);
+            if (us < 0) { printf("groupnorm graph capture / replay failed\n"); return 1; }
+            tt[v].push_back(us);
+          }
+        if (tt[1].empty()) continue;
+        hipMemset(mism, 0, 8); hipMemset(maxabs, 0, 4); hipMemset(maxref, 0, 4);
+        const size_t n = (size_t)R * s3[0] * s3[1];
+        hipLaunchKernelGGL(diff_kernel, dim3(256), dim3(256), 0, 0, o1, o0, n, mism, maxabs, maxref);
+        unsigned long long nm_ = 0; float ma = 0, mr = 0;
+        hipMemcpy(&nm_, mism, 8, hipMemcpyDeviceToHost); hipMemcpy(&ma, maxabs, 4, hipMemcpyDeviceToHost); hipMemcpy(&mr, maxref, 4, hipMemcpyDeviceToHost);
+        std::sort(tt[0].begin(), tt[0].end()); std::sort(tt[1].begin(), tt[1].end());
+        printf("groupnorm (%d, %d, %d) x%-2d two launches %7.1f us   single launch %7.1f us   differing %llu of %zu, max |d| %.3g (max |ref| %.3g)\n",
+               R, s3[0], s3[1], s3[2], tt[0][tt[0].size() / 2], tt[1][tt[1].size() / 2], nm_, n, ma, mr);
+        tot[0] += s3[2] * tt[0][tt[0].size() / 2]; tot[1] += s3[2] * tt[1][tt[1].size() / 2];
       }
-      printf("  forward-weighted GroupNorm time at %d rows: %.2f ms\n", R, tot / 1e3);
+      idf_set_tuning(IDF_TUNE_GN_FUSED, 0);
+      printf("  forward-weighted GroupNorm time at %d rows: two launches %.2f ms, single launch %.2f ms (single launch applies at B <= 8 only)\n", R, tot[0] / 1e3, tot[1] / 1e3);
       hipFree(gws);
     }
-    printf("  forward-weighted GEMM + conv time at %d rows: base %.2f ms, ring everywhere %.2f ms;", R, tot0 / 1e3, tot1 / 1e3);
-    for (int i = 0; i < 5; ++i) printf("  thr %d: %.2f", thresholds[i], tot_thr[i] / 1e3);
-    printf(" ms\n");
+    printf("  forward-weighted GEMM + conv time at %d rows: round-3 dispatch %.2f ms, + latency kernel (<= 256 tiles) %.2f, persistent kernel forced %.2f, "
+           "latency kernel + 50 %% bar %.2f, best of the four per shape %.2f ms\n", R, totv[0] / 1e3, totv[1] / 1e3, totv[2] / 1e3, totv[3] / 1e3, totbest / 1e3);
+    (void)tot0; (void)tot1; (void)tot_thr; (void)thresholds;
   }
   idf_set_tuning(IDF_TUNE_GEMM_RING, 0);
   return 0;

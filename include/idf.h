@@ -73,15 +73,12 @@ const char* idf_build_info(void);
  *   ring that has its K-tiles in flight from the first instruction instead of one at a time -- when their tile grid has at most
  *   `value` tiles; 0 = never.  Same tiles, same K order: the result bits do not depend on it unless the split-K choice differs.
  *   Initial value: env IDF_GEMM_RING or the library default.
- *   IDF_TUNE_GN_FUSED (round 4): 1 = idf_groupnorm runs small batches (B <= 8, <= 256 workgroups) as ONE launch (statistics,
- *   device-wide rendezvous per sample, normalisation); 0 = always the two launches.  Initial value: env IDF_GN_FUSED or the
- *   library default.
  *   IDF_TUNE_BIG_MIN_EFF (round 4): occupancy bar of IDF_TUNE_GEMM_BIG's automatic rule in per cent (1..100): the persistent
  *   kernel takes a launch whose tile grid fills at least this share of the workgroup slots of its last round.  Initial value:
  *   env IDF_BIG_MIN_EFF or the library default.
  * (ABI 2 also exposed the kernel variants that were measured slower -- GEMM geometries 1..6, attention modes 1..14; they
  * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.) */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_GN_FUSED = 3, IDF_TUNE_BIG_MIN_EFF = 4 };
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2 };
@@ -203,11 +200,7 @@ typedef struct {
 int idf_attention(const idf_attn_args* a, void* stream);
 
 /* ---- GroupNorm(32 groups) (+SiLU), fp32 statistics (util.py:223-226; attention.py:75-76) -----------------
- * x/out: [B, HW, C] 16-bit.  ws: f32 workspace of idf_groupnorm_ws_floats(B, HW) floats, ZERO-FILLED ONCE before its first
- * use (round 4): its last 2 B words are the arrival / departure counters of the single-launch form small batches take
- * (B <= 8 and at most 256 workgroups: statistics, a device-wide rendezvous per sample, normalisation -- one launch instead of
- * two); every launch leaves them zero again.  One workspace serves one stream at a time.  A workspace that was never zeroed
- * cannot hang the device (the rendezvous gives up after ~0.5 s) but the output of that launch is then undefined.       */
+ * x/out: [B, HW, C] 16-bit.  ws: f32 workspace of idf_groupnorm_ws_floats(B, HW) floats.                    */
 long long idf_groupnorm_ws_floats(int B, int HW);
 int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
                   int B, int HW, int C, float eps, int silu, int dtype, void* stream);

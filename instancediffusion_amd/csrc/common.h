@@ -111,4 +111,3 @@ static inline int idf_launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
-int idf_gn_fused_set(int v);                                    // norms.hip: single-launch GroupNorm for small batches on / off

@@ -915,10 +915,6 @@ extern "C" int idf_set_tuning(int knob, int value) {
     if (value < 1 || value > 100) return IDF_E_ARG;
     return idf_big_min_eff_pct(value);
   }
-  if (knob == IDF_TUNE_GN_FUSED) {
-    if (value < 0 || value > 1) return IDF_E_ARG;
-    return idf_gn_fused_set(value);
-  }
   if (knob == IDF_TUNE_ATTN2) {
     if (value < 0 || value > 3) return IDF_E_ARG;
     return idf_attn2_set_mode(value);

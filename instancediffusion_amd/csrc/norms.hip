@@ -13,18 +13,12 @@
 namespace {
 
 constexpr int GN_GROUPS = 32;
-constexpr int GN_MAX_CHUNKS = 64;     // row-chunks per batch element (large batches)
-constexpr int GN_MAX_CHUNKS_SMALL = 256;
+constexpr int GN_MAX_CHUNKS = 64;     // row-chunks per batch element
 
-// Row chunks per batch element: HW / 32, at most 64 -- and for SMALL batches (B x chunks < 512 workgroups: the 2-row forwards
-// of BASELINE config 2) finer, down to 8 rows per chunk and at most 256 chunks: there the statistics pass is a chain of
-// dependent trips to memory per thread (rows / (TY x 4) of them, ~10 us for a 64 x 64 x 320 sample on 128 workgroups), not
-// bandwidth.  A function of (B, HW) only, so a given launch shape always reduces in the same order (bitwise reproducible).
-inline int gn_nchunks(int B, int HW) {
+__host__ __device__ inline int gn_nchunks(int HW) {
   int n = HW / 32;
   if (n < 1) n = 1;
   if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
-  while ((long long)B * n < 512 && HW / (2 * n) >= 8 && 2 * n <= GN_MAX_CHUNKS_SMALL) n *= 2;
   return n;
 }
 
@@ -41,9 +35,9 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 
 // partial[b][chunk][g][2] = (mean, M2) over the rows of the chunk (count = rows in the chunk x channels per group)
 template <int DT, int UNR>
-__device__ __forceinline__ void gn_stats_body(float* sm /* [2][TY][C]: mean, M2 per (row lane, channel) */,
-                                              const unsigned short* __restrict__ x, float* __restrict__ partial,
-                                              int HW, int C, int nchunks) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ partial,
+                                                      int HW, int C, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [2][TY][C]: mean, M2 per (row lane, channel)
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cpr = C >> 3;                                        // 16-B chunks per row
   const int TX = cpr < 256 ? cpr : 256;
@@ -118,24 +112,11 @@ __device__ __forceinline__ void gn_stats_body(float* sm /* [2][TY][C]: mean, M2 
 }
 
 template <int DT, int UNR>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ partial,
-                                                      int HW, int C, int nchunks) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  gn_stats_body<DT, UNR>(sm, x, partial, HW, C, nchunks);
-}
-
-// `partial` is read through PLOAD: a plain load in the two-launch form, a device-scope atomic load in the single-launch form
-// (the partials were written by other workgroups of the SAME launch, possibly on another XCD with its own L2)
-template <int DT, int UNR, bool COHERENT>
-__device__ __forceinline__ void gn_apply_body(float* sm /* scale[C], shift[C], mean[32], rstd[32] */,
-                                              const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
-                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                              const float* partial, int HW, int C, int nchunks,
-                                              float eps, int silu, int nblk_x) {
-  auto PLOAD = [](const float* q) -> float {
-    if constexpr (COHERENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *q;
-  };
+__global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ partial, int HW, int C, int nchunks,
+                                                      float eps, int silu, int nblk_x) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // scale[C], shift[C], mean[32], rstd[32]
   float* sc = sm;
   float* sh = sm + C;
   float* mean = sm + (2 * C > 512 ? 2 * C : 512);                // the first 2 KB double as the fp64 reduction scratch
@@ -154,7 +135,7 @@ __device__ __forceinline__ void gn_apply_body(float* sm /* scale[C], shift[C], m
     double acc = 0.0;
     for (int k = part; k < nchunks; k += 256 / GN_GROUPS) {
       const int rows_k = min(HW, (k + 1) * rows_per_c) - min(HW, k * rows_per_c);
-      acc += (double)rows_k * (double)cpg * (double)PLOAD(partial + (((size_t)b * nchunks + k) * GN_GROUPS + g) * 2);
+      acc += (double)rows_k * (double)cpg * (double)partial[(((size_t)b * nchunks + k) * GN_GROUPS + g) * 2];
     }
     red[part * GN_GROUPS + g] = acc;
     __syncthreads();
@@ -167,8 +148,8 @@ __device__ __forceinline__ void gn_apply_body(float* sm /* scale[C], shift[C], m
     for (int k = part; k < nchunks; k += 256 / GN_GROUPS) {
       const int rows_k = min(HW, (k + 1) * rows_per_c) - min(HW, k * rows_per_c);
       const float* pp = partial + (((size_t)b * nchunks + k) * GN_GROUPS + g) * 2;
-      const double d = (double)PLOAD(pp) - mu;
-      acc += (double)PLOAD(pp + 1) + (double)rows_k * (double)cpg * d * d;
+      const double d = (double)pp[0] - mu;
+      acc += (double)pp[1] + (double)rows_k * (double)cpg * d * d;
     }
     red[part * GN_GROUPS + g] = acc;
     __syncthreads();
@@ -226,50 +207,6 @@ __device__ __forceinline__ void gn_apply_body(float* sm /* scale[C], shift[C], m
         }
         *reinterpret_cast<u32x4*>(ob + (size_t)r * C + cc * 8) = pack8<DT>(f);
       }
-    }
-  }
-}
-
-template <int DT, int UNR>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ partial, int HW, int C, int nchunks,
-                                                      float eps, int silu, int nblk_x) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  gn_apply_body<DT, UNR, false>(sm, x, out, gamma, beta, partial, HW, C, nchunks, eps, silu, nblk_x);
-}
-
-// Single-launch form for small batches (B x chunks <= 256 workgroups, all resident at once): statistics of the workgroup's
-// row chunk -> partial; arrive on the sample's counter; wait until all `nchunks` workgroups of the sample have arrived; merge
-// the partials and normalise the SAME chunk (its second read is an L2 / Infinity-Cache hit a few microseconds after the
-// first).  One launch instead of two for the ~60 GroupNorms of a forward whose cost at 2 rows is launches, not bytes.
-// sync[2 b] = arrivals, sync[2 b + 1] = departures; the last workgroup to depart zeroes both, so a workspace that was zero
-// before its first use stays valid for every later launch (idf_groupnorm's contract).  The wait is bounded: a workspace that
-// was NOT zeroed makes the launch give up after ~0.5 s with wrong output instead of hanging the device.
-template <int DT, int UNR>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float* partial, unsigned* sync, int HW, int C, int nchunks,
-                                                      float eps, int silu) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  gn_stats_body<DT, UNR>(sm, x, partial, HW, C, nchunks);
-  __threadfence();                                               // this workgroup's partial is visible device-wide ...
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(sync + 2 * b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ... before it arrives
-    int spins = 0;
-    while (__hip_atomic_load(sync + 2 * b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nchunks && ++spins < (1 << 22))
-      __builtin_amdgcn_s_sleep(4);
-  }
-  __syncthreads();
-  gn_apply_body<DT, UNR, true>(sm, x, out, gamma, beta, partial, HW, C, nchunks, eps, silu, nchunks);
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned gone = __hip_atomic_fetch_add(sync + 2 * b + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == (unsigned)nchunks - 1u) {                        // every workgroup of the sample has read the partials
-      __hip_atomic_store(sync + 2 * b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sync + 2 * b + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -339,36 +276,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const unsigned short* __restric
   }
 }
 
-// row chunks of the single-launch form: every workgroup of the launch must be resident at once (<= 256 of them), small batches only
-inline int gn_nchunks_fused(int B, int HW) {
-  if (B > 8) return 0;
-  int n = HW / 32;
-  if (n < 1) n = 1;
-  if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
-  if ((long long)B * n > 256) return 0;
-  while ((long long)B * n * 2 <= 256 && HW / (2 * n) >= 8) n *= 2;
-  return n;
-}
-#ifndef IDF_GN_FUSED_DEFAULT
-#define IDF_GN_FUSED_DEFAULT 0
-#endif
-int g_gn_fused = -1;
-inline int gn_fused_mode() {
-  if (g_gn_fused < 0) { const char* e = getenv("IDF_GN_FUSED"); g_gn_fused = e ? (atoi(e) != 0) : IDF_GN_FUSED_DEFAULT; }
-  return g_gn_fused;
-}
-
 }  // namespace
 
-int idf_gn_fused_set(int v) {                                   // idf_set_tuning(IDF_TUNE_GN_FUSED): returns the previous value
-  const int prev = gn_fused_mode();
-  g_gn_fused = v != 0;
-  return prev;
-}
-
-// [B][chunks][32][2] partial (mean, M2) + 2 B counters of the single-launch form (zero before the first use, see idf.h)
 extern "C" long long idf_groupnorm_ws_floats(int B, int HW) {
-  return (long long)B * gn_nchunks(B, HW) * GN_GROUPS * 2 + 2LL * B;
+  return (long long)B * gn_nchunks(HW) * GN_GROUPS * 2;
 }
 
 extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
@@ -377,33 +288,17 @@ extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const
   if (B <= 0 || HW <= 0 || C <= 0 || (C % 32) || (C % 8)) return IDF_E_ARG;
   if (!aligned16(x) || !aligned16(out)) return IDF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  const int nchunks = gn_nchunks(B, HW);
+  const int nchunks = gn_nchunks(HW);
   const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
   const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
   const size_t sm2 = (size_t)((2 * C > 512 ? 2 * C : 512) + 2 * GN_GROUPS) * sizeof(float);
   if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
   int nblk = (HW + TY * 8 - 1) / (TY * 8);                       // >= 8 rows per thread-row, <= 256 blocks per batch
-  if ((long long)B * nblk < 512) nblk = (HW + TY * 4 - 1) / (TY * 4);   // small batch: one trip of 4 rows in flight per thread
   if (nblk < 1) nblk = 1;
   if (nblk > 256) nblk = 256;
   dim3 g1(nchunks, B), g2(nblk, B);
   static int unr = -1;                                          // rows in flight per thread (IDF_GN_UNROLL=1|4 for A/B runs)
   if (unr < 0) { const char* e = getenv("IDF_GN_UNROLL"); unr = (e && atoi(e) == 1) ? 1 : 4; }
-  const int nf = gn_fused_mode() ? gn_nchunks_fused(B, HW) : 0;
-  if (nf > 0 && unr == 4) {                                      // small batch: statistics + normalisation in ONE launch
-    unsigned* sync = reinterpret_cast<unsigned*>(ws + (size_t)B * nchunks * GN_GROUPS * 2);
-    const size_t smf = sm1 > sm2 ? sm1 : sm2;
-    dim3 gf(nf, B);
-    if (dtype == IDF_BF16)
-      hipLaunchKernelGGL((gn_fused_kernel<IDF_BF16, 4>), gf, dim3(256), smf, s, (const unsigned short*)x, (unsigned short*)out, gamma, beta,
-                         ws, sync, HW, C, nf, eps, silu);
-    else if (dtype == IDF_F16)
-      hipLaunchKernelGGL((gn_fused_kernel<IDF_F16, 4>), gf, dim3(256), smf, s, (const unsigned short*)x, (unsigned short*)out, gamma, beta,
-                         ws, sync, HW, C, nf, eps, silu);
-    else
-      return IDF_E_UNSUPPORTED;
-    return idf_launch_status();
-  }
 #define IDF_GN_LAUNCH(DT, U)                                                                                              \
   hipLaunchKernelGGL((gn_stats_kernel<DT, U>), g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);      \
   hipLaunchKernelGGL((gn_apply_kernel<DT, U>), g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,     \

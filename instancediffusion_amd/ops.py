@@ -50,8 +50,7 @@ class HipOps:
         k = (key, int(nfloats))
         w = self._ws.get(k)
         if w is None:
-            # zero-filled: idf_groupnorm keeps self-resetting rendezvous counters in the tail of its workspace (include/idf.h)
-            w = torch.zeros(int(nfloats), dtype=torch.float32, device=self.device)
+            w = torch.empty(int(nfloats), dtype=torch.float32, device=self.device)
             self._ws[k] = w
         return w
 

@@ -51,8 +51,7 @@ def test_argument_validation_without_gpu():
     t = _lib.AttnArgs()
     assert lib.idf_attention(ctypes.byref(t), None) == -1
     assert lib.idf_layernorm(None, 0, None, 0, None, None, 1, 8, 1e-5, 0, None) == -1
-    assert lib.idf_groupnorm_ws_floats(128, 4096) == 128 * 64 * 32 * 2 + 2 * 128     # partials + 2 B rendezvous counters
-    assert lib.idf_groupnorm_ws_floats(2, 4096) == 2 * 256 * 32 * 2 + 4        # small batches: finer row chunks (round 4)
+    assert lib.idf_groupnorm_ws_floats(2, 4096) == 2 * 64 * 32 * 2
     assert lib.idf_softmax_rows(None, None, 4, 64, 64, 64, 1.0, 0, None) == -1
     assert lib.idf_pointwise_nchw(None, None, None, None, 1, 4, 4, 16, 1.0, None) == -1
     with pytest.raises(_lib.IdfError):
@@ -103,7 +102,7 @@ def test_argument_validation_without_gpu():
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ln_stats=0x20004)), None) == -2
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ldw2=640)), None) == -1                # rows of W2 shorter than 4C
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
-    assert lib.idf_set_tuning(5, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
+    assert lib.idf_set_tuning(4, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
     prev = lib.idf_set_tuning(1, 2)
     assert prev in (0, 1, 2, 3) and lib.idf_set_tuning(1, prev) == 2
     # round 4: tile-count threshold of the latency kernel (0 = never), and its launch counter
@@ -114,9 +113,6 @@ def test_argument_validation_without_gpu():
     assert lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 0) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 101) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 60)
     assert 1 <= prev <= 100 and lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, prev) == 60
-    assert lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 2) == -1
-    prev = lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 1)
-    assert prev in (0, 1) and lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, prev) == 1
 
 
 def test_fuser_type_values_of_the_reference_are_accepted():

@@ -307,42 +307,6 @@ def test_groupnorm_large_mean_over_std(ops, B, HW, C):
     assert err < 6e-3                                           # one bf16 rounding of outputs up to ~1.23 is 3.9e-3
 
 
-@pytest.fixture
-def gn_fused():
-    """Single-launch GroupNorm for small batches switched on (idf_set_tuning) for the duration of a test."""
-    from instancediffusion_amd import _lib
-    lib = _lib.load()
-    prev = lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 1)
-    yield
-    lib.idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, prev)
-
-
-@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 64, True), (1, 4096, 320, True), (2, 64, 2560, True), (2, 4096, 320, True),
-                                         (3, 1024, 960, False), (1, 144, 1920, True), (2, 16, 128, False), (8, 1024, 640, True)])
-def test_groupnorm_single_launch(ops, ref, gn_fused, B, HW, C, silu):
-    """The small-batch form (statistics + device-wide rendezvous per sample + normalisation in one launch) against the same
-    reference and, repeated on the same workspace, bit for bit against itself: the rendezvous counters must reset."""
-    test_groupnorm(ops, ref, B, HW, C, silu)
-    x = to16(gen((B, HW, C), 56) * 0.8 - 0.2)
-    gm, bt = 1 + 0.1 * gen((C,), 57), 0.1 * gen((C,), 58)
-    want = ref.groupnorm(x.float(), torch.empty(B, HW, C), gm, bt, 1e-5, silu)
-    outs = [ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, silu) for _ in range(20)]
-    torch.cuda.synchronize()
-    assert relmax(outs[0], want) < BF16_TOL
-    assert all(torch.equal(o, outs[0]) for o in outs[1:])
-    # ... and the two-launch form gives the same statistics up to their fp32 merge order
-    from instancediffusion_amd import _lib
-    _lib.load().idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 0)
-    two = ops.groupnorm(dev(x), ops.empty((B, HW, C)), dev(gm), dev(bt), 1e-5, silu)
-    torch.cuda.synchronize()
-    _lib.load().idf_set_tuning(_lib.IDF_TUNE_GN_FUSED, 1)
-    assert relmax(outs[0], two) < BF16_TOL
-
-
-def test_groupnorm_single_launch_large_mean(ops, gn_fused):
-    test_groupnorm_large_mean_over_std(ops, 2, 1000, 640)
-
-
 @pytest.mark.parametrize("M,C", [(4096, 320), (1000, 640), (77, 1280), (5, 64), (184, 128)])
 def test_layernorm(ops, ref, M, C):
     x = to16(gen((M, C), 53) * 2 + 0.3)

@@ -1,13 +1,15 @@
-// A/B harness for the small-batch GEMM / conv launches through the C ABI, torch-free: every dense GEMM and 3x3 conv shape of
-// an R-row UNet forward (R = 2: BASELINE config 2; R = 16: the second MIS phase of the reference's own 8-image batch) is
-// launched with the latency kernel off (IDF_TUNE_GEMM_RING = 0: K-loop variants 1 / 2) and on (threshold = every tile grid),
-// interleaved per shape in one process.  Prints the median time of each, the launch weight of the shape in one forward and
-// how far the two outputs are apart (same tiles and K order: bit-identical unless the split-K choice differs), then the
-// forward-weighted totals per threshold candidate.
+// A/B harness for the dispatch of the small and mid-size GEMM / conv launches, through the C ABI, torch-free: every dense GEMM
+// and 3x3 conv shape of an R-row UNet forward (R = 2: BASELINE config 2; 16: the second MIS phase of the reference's own
+// 8-image batch; 64 / 128: the bench's forwards) under four dispatch settings, interleaved per shape in one process:
+// round-3 dispatch / + latency kernel for grids of <= 256 tiles / persistent kernel forced / latency kernel + 50 % occupancy
+// bar (the round-4 default).  Every launch of a shape reads ANOTHER weight matrix (cold weights, as in a forward) and the time
+// is the GPU time of a captured graph of `reps` launches.  Prints the median per setting, then the forward-weighted totals;
+// the GroupNorms of the same forward are timed at the end of each block.  (Bitwise agreement of the kernels is the GPU suite's
+// business: tests/test_kernels_gpu.py::test_gemm_ring_*.)
 // Build (from the repo root):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/ubench/small_shapes.hip -Linstancediffusion_amd -l:libidf_gfx950.so \
 //         -Wl,-rpath,'$ORIGIN/../../instancediffusion_amd' -o tools/ubench/small_shapes
-// Run: tools/ubench/small_shapes [reps] [rounds]
+// Run: tools/ubench/small_shapes [reps] [rounds] [largest R: 16 | 64 | 128]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -16,19 +18,6 @@
 #include <cstring>
 #include <vector>
 #include "idf.h"
-
-__global__ void diff_kernel(const unsigned short* a, const unsigned short* b, size_t n, unsigned long long* mism, float* maxabs, float* maxref) {
-  unsigned long long c = 0; float mx = 0.f, mr = 0.f;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float x = __uint_as_float((unsigned)a[i] << 16), y = __uint_as_float((unsigned)b[i] << 16);
-    if (a[i] != b[i]) ++c;
-    if (!(fabsf(x - y) <= mx)) mx = fabsf(x - y);              // NaN propagates
-    mr = fmaxf(mr, fabsf(y));
-  }
-  atomicAdd(mism, c);
-  atomicMax(reinterpret_cast<unsigned*>(maxabs), __float_as_uint(mx));      // non-negative floats order like their bits
-  atomicMax(reinterpret_cast<unsigned*>(maxref), __float_as_uint(mr));
-}
 
 struct Shape { const char* name; int count; bool conv; int M, N, K, epi; int H, Cin, stride, up; };
 
@@ -61,8 +50,6 @@ int main(int argc, char** argv) {
   const size_t W_ELEMS = (size_t)512 << 20;
   unsigned short *a, *w, *o0, *o1, *r;
   float *bias, *ws, *stats, *lnc;
-  unsigned long long* mism; float *maxabs, *maxref;
-  hipMalloc(&mism, 8); hipMalloc(&maxabs, 4); hipMalloc(&maxref, 4);
   hipMalloc(&a, max_elems * 2); hipMalloc(&o0, max_elems * 2); hipMalloc(&o1, max_elems * 2); hipMalloc(&r, max_elems * 2);
   hipMalloc(&w, W_ELEMS * 2); hipMalloc(&bias, 32768 * 4); hipMalloc(&lnc, 32768 * 4); hipMalloc(&ws, (size_t)256 << 20);
   hipMalloc(&stats, (size_t)RMAX * 4096 * 2 * 4);

@@ -811,11 +811,15 @@ int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
   CoreParams q = p;
   q.splitk = 1; q.kt_per_slice = nk;
   q.tail_m0 = 0; q.tail_rows = p.M;
-  // split-K towards one workgroup per CU (this kernel's occupancy), slices of >= 4 K-tiles: a slice then has its whole K
-  // range in flight at once and the launch is one trip to memory plus the reducer
-  if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles * 2 <= slots && nk >= 8) {
+  // split-K towards one workgroup per CU (this kernel's occupancy), slices of >= 8 K-tiles (two to three trips to memory with
+  // the ring's depth) plus the reducer
+  // least K-tiles per slice: 8 (IDF_RING_SLICE_KT for A/B runs; 4 / 8 / 16 / 32 give 5.49 / 5.29 / 5.73 / 6.07 ms of GEMM + conv
+  // per 2-row forward, profiles/r04_ring_slice_length.log: shorter slices pay more reducer traffic than their parallelism buys)
+  static int slice_kt = 0;
+  if (slice_kt == 0) { const char* e = getenv("IDF_RING_SLICE_KT"); slice_kt = e ? atoi(e) : 8; if (slice_kt < 1) slice_kt = 8; }
+  if (batch == 1 && p.ws && !(p.epi & IDF_EPI_GEGLU) && tiles * 2 <= slots && nk >= 2 * slice_kt) {
     int want = slots / tiles;
-    if (want > nk / 4) want = nk / 4;
+    if (want > nk / slice_kt) want = nk / slice_kt;
     if (want > 64) want = 64;
     while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > p.ws_bytes) --want;
     if (want > 1) {

@@ -197,9 +197,9 @@ def measure_roofline(engine, batch, fuser_on=True):
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     name, d = dom
     kern = {"conv3x3": "gemm_kernel_big<.., CONV=true> (persistent 256x320 implicit-GEMM 3x3 conv, LDS-DMA gather; "
-                       "gemm_kernel<..,true> + split-K below 8^2)",
+                       "gemm_kernel_ring<..,true> + split-K for small grids)",
             "gemm": "gemm_kernel_big<.., CONV=false> (persistent 256x{320,256}-tile dense GEMM, LDS-DMA staging, in-register "
-                    "epilogue; gemm_kernel_dma 128x128 for batched / badly quantised shapes) + mlp320_kernel2 (the C = 320 GEGLU "
+                    "epilogue; gemm_kernel_ring / gemm_kernel_dma 128x128 for small grids and batched launches) + mlp320_kernel (the C = 320 GEGLU "
                     "feed-forwards, both products in one launch)",
             "attention": "attn4_kernel<DT,3,2,1> for d=40 (64 queries/wave, LDS-DMA K / V^T rings, max-free softmax, XCD-aware "
                          "grid) / attn_kernel for d=80,160 and the 77-key cross-attention"

@@ -615,6 +615,9 @@ int idf_launch_attn4(const AttnParams& p, int B, int dtype, hipStream_t s) {
   if ((p.ldk[0] % 8) || (p.ldv[0] % 8) || (p.n[1] > 0 && ((p.ldk[1] % 8) || (p.ldv[1] % 8)))) return IDF_ATTN2_UNSUPPORTED;
   if (!aligned16(p.k[0]) || !aligned16(p.vt[0]) || !aligned16(p.k[1]) || !aligned16(p.vt[1])) return IDF_ATTN2_UNSUPPORTED;
   if ((p.sK[0] % 8) || (p.sV[0] % 8) || (p.sK[1] % 8) || (p.sV[1] % 8)) return IDF_ATTN2_UNSUPPORTED;
+  // the LDS-transposed epilogue stores O (and reads Q) as 16-B vectors: rows and batch strides must keep that alignment, else
+  // the 32-query kernel (8-B stores, idf_attention's own ldo % 4 contract) takes the launch
+  if (!aligned16(p.out) || (p.ldo % 8) || (p.sO % 8) || !aligned16(p.q) || (p.ldq % 8) || (p.sQ % 8)) return IDF_ATTN2_UNSUPPORTED;
   // per-lane DMA offsets are 32-bit: a (batch, head) slice of K / V^T must stay below 4 GB
   if ((long long)KVT * p.ldk[0] * 2 >= (1ll << 31) || (long long)(p.d + 8) * p.ldv[0] * 2 >= (1ll << 31)) return IDF_ATTN2_UNSUPPORTED;
   if (p.n[1] > 0 && ((long long)KVT * p.ldk[1] * 2 >= (1ll << 31) || (long long)(p.d + 8) * p.ldv[1] * 2 >= (1ll << 31)))

@@ -783,6 +783,25 @@ def test_attention_v2(ops, ref, attn2, B, H, d, Nq, n0, n1):
     assert relmax(out, want) < 2 * BF16_TOL
 
 
+def test_attention_v2_declines_an_output_it_cannot_store_with_16_byte_vectors(ops, ref, attn2):
+    """the 64-query kernel's epilogue writes O as 16-B vectors; an output whose row stride is only 8-B aligned
+    (ldo % 8 == 4, legal for idf_attention) must go to the 32-query kernel instead of being written misaligned."""
+    B, H, d, N = 1, 8, 40, 256
+    C = H * d
+    q, k0, v0 = to16(gen((B, N, C), 140)), to16(gen((B, N, C), 141)), to16(gen((B, N, C), 142))
+    vt0 = v0.transpose(1, 2).contiguous()
+    want = ref.attention(q.float(), k0.float(), vt0.float(), N, torch.empty(B, N, C), H)
+    wide = ops.zeros((B, N, C + 4))                              # ldo = 324: rows 8-B aligned only
+    out = ops.attention(dev(q), dev(k0), dev(vt0), N, wide[:, :, :C], H)
+    torch.cuda.synchronize()
+    assert attn2() == 0, "the launch must have gone to the 32-query kernel"
+    assert relmax(out, want) < 2 * BF16_TOL
+    assert float(wide[:, :, C:].float().abs().max()) == 0.0
+    out2 = ops.attention(dev(q), dev(k0), dev(vt0), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    assert attn2() == 1 and relmax(out2, want) < 2 * BF16_TOL
+
+
 def test_attention_v2_forced_rescale_and_strided_views(ops, ref, attn2):
     """Late spike (rescale branch after many alpha == 1 tiles) on q/k column slices of a fused projection buffer."""
     B, H, d, N = 2, 8, 40, 640

@@ -1,8 +1,4 @@
 #!/bin/bash
 # scratch: GPU call script of the moment (see tools/gpu_call.sh for the runner)
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
-for w in default 1; do
-  echo "== IDF_TILE_WIDE=$w"
-  if [ $w = default ]; then timeout 300 tools/ubench/small_shapes 20 3 16 > /tmp/o.txt; else IDF_TILE_WIDE=$w timeout 300 tools/ubench/small_shapes 20 3 16 > /tmp/o.txt; fi
-  grep -E "N320 |forward-weighted GEMM" /tmp/o.txt | cut -c1-175
-done
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -p no:cacheprovider -k "ring or attention_v2_declines" 2>&1 | tail -4

@@ -12,7 +12,7 @@ guidance 7.5, N=8 box instances, Multi-instance Sampler mis=0.36 (=> 406 UNet fo
 images per step; ``--images-total K`` fixes the global batch instead (strong scaling, e.g. 8 images on 1 / 2 / 4 / 8 GPUs).
 At n_gpus > 1 the (instance, image) work units of MIS phase 1 are sharded over the ranks by ``--sharding``: "instance"
 (default; owner = (image + instance) mod N: the N+1 trajectories of every image are spread over the GPUs and ONE RCCL
-all-reduce of the disjoint [instance][image] latent stack -- a gather -- recombines them before the same idf_mis_merge
+all-gather of the unit latents each rank owns recombines them, in the fixed [instance][image] order, before the same idf_mis_merge
 call as on one GPU: north_star's split) or "image" (owner = image mod N: replicas, nothing to exchange at the merge).  Inputs are resident in HBM before the timed region.  VAE decode is outside the path.
 
 Prints ONE JSON line on rank 0 with the driver contract fields plus
@@ -388,8 +388,8 @@ def main():
                        "images_per_gpu": None if args.images_total else args.images_per_gpu,
                        "global_images_per_step": n_images, "unet_forwards_per_image": nf,
                        "sharding": args.sharding if world > 1 else "none (1 GPU)",
-                       "parallelism": f"MIS (instance, image) units sharded x{world} [{args.sharding}], one RCCL all-reduce (gather "
-                                      f"of the instance latents) at the merge; phase 2 sharded over images x{world}"},
+                       "parallelism": f"MIS (instance, image) units sharded x{world} [{args.sharding}], one RCCL all-gather of the "
+                                      f"owned instance latents at the merge; phase 2 sharded over images x{world}"},
             # reference-algorithmic work: every forward the reference runs (406 per image) at its own 1227.3 GFLOP
             "whole_step_algorithmic_tflops_per_gpu": round(value * nf * GFLOP_PER_FWD / 1e3 / world, 1),
             "whole_step_frac_of_mfma_peak": round(value * nf * GFLOP_PER_FWD / 1e3 / world / PEAK_MFMA_TF, 4),

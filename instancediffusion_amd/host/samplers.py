@@ -9,8 +9,8 @@ constructor / ``sample()`` API, same schedule, same update rule and quirks, diff
   * everything step-invariant lives in ``engine.Cond`` objects built once per ``sample()`` call;
   * latents, eps history and the PLMS/CFG arithmetic stay on the GPU in fp32 (fused kernels);
   * with ``torch.distributed`` initialised (one process per GPU, RCCL), MIS phase 1 is sharded over
-    (instance, image) work units, the instance latents are recombined by ONE all-reduce of the disjoint
-    [instance][image] latent stack (a gather: every element has exactly one non-zero contributor) and merged by the
+    (instance, image) work units, the instance latents are recombined by ONE all-gather of the unit latents each rank owns
+    (scattered by index into the fixed [instance][image] stack: pure data movement) and merged by the
     same ``idf_mis_merge`` call as on one rank -- outputs are bit-identical at every world size -- and phase 2 is
     sharded over images.
 """
@@ -223,7 +223,7 @@ class PLMSSamplerInst(_PLMSBase):
         # is independent of the world size (weak scaling); used when the images divide evenly over the ranks.
         # "instance" sharding: owner = (b + j) % world -- spreads the N+1 trajectories of FEW images (B < world, e.g. one
         # image on 8 GPUs) over the ranks; the owner of image b (rank b % world) still runs (0, b), whose eps history
-        # continues into phase 2.  Either way the merge is one small all-reduce.
+        # continues into phase 2.  Either way the merge is at most one small all-gather.
         mode = self.unit_sharding
         if mode == "auto":
             mode = "image" if (B % world == 0) else "instance"
@@ -347,9 +347,8 @@ class PLMSSamplerInst(_PLMSBase):
 
         # ---------------- merge (plms_instance.py:128-135) ------------------------------------------------------
         # The SAME arithmetic at every world size: the N+1 unit latents of every image are laid out in the fixed order
-        # [instance][image] and idf_mis_merge reduces them (mean, or crop-and-paste) -- a rank fills in the units it ran,
-        # zeros elsewhere, and ONE all-reduce (RCCL) of that stack recombines the instance latents: the supports are
-        # disjoint, x + 0 is exact, so the sum IS a gather and the merged latent is bit-identical to the 1-rank result.
+        # [instance][image] and idf_mis_merge reduces them (mean, or crop-and-paste) -- a rank fills in the units it ran and
+        # ONE all-gather (RCCL) brings in the others' (below): the merged latent is bit-identical to the 1-rank result.
         # With `image` ownership a rank holds every unit of the images it continues in phase 2: nothing to exchange.
         lat = torch.zeros((n_all, B) + tuple(shape[1:]), device=dev, dtype=torch.float32)
         for (j, b), xv in x_units.items():

@@ -194,6 +194,35 @@ def test_fused_qkv_projection_equals_the_two_gemm_form():
     assert cases.rel_rms(outs[0], want) < 3e-4
 
 
+def test_fused_mlp_is_used_from_its_row_threshold_and_equals_the_two_gemm_form(monkeypatch):
+    """engine._ff sends the GEGLU feed-forward of a C = 320 block to the fused kernel (ops.mlp_geglu) only from
+    ``engine.MLP_MIN_M`` token rows up -- below, the kernel's 128-row tiles no longer fill the chip and the two GEMMs are faster
+    (profiles/r04_mlp_small_m.log).  Same forward either way; call counts checked (3-level model, 32x32 latent: the 320-channel
+    level has 2 x 1024 rows)."""
+    import instancediffusion_amd.engine as E
+    cfg = cases.cfg_for("test_box.yaml", "mid")
+    model = build_model(cfg)
+    g = torch.Generator().manual_seed(22)
+    gb = synth.make_grounding_batch(2, synth.random_boxes(3, g), g)
+    x = torch.randn(2, 4, 32, 32, generator=g)
+    ctx = torch.randn(2, 77, 768, generator=g)
+    t = torch.tensor([700.0, 300.0])
+    grounding = GroundingNetInput().prepare(gb)
+    outs, calls = [], []
+    with torch.no_grad():
+        for min_m in (2048, 2049):                               # M = 2 x 1024 rows at the 320-channel level
+            monkeypatch.setattr(E, "MLP_MIN_M", min_m)
+            ops = EmulOps(torch.float32)
+            eng = UNetEngine(model, ops=ops, use_graphs=False)
+            cond = eng.prepare_cond(ctx, grounding)
+            before = ops.calls.get("mlp_geglu", 0)
+            outs.append(eng.forward_cond(x, t, cond))
+            calls.append(ops.calls.get("mlp_geglu", 0) - before)
+            n_top = sum(1 for p in eng._st_layers() if p["c"] == 320)
+    assert E.MLP_FUSED and calls == [2 * n_top, 0] and n_top > 0          # the fuser's feed-forward and the block's own, per layer
+    assert cases.rel_rms(outs[0], outs[1]) < 1e-5
+
+
 @pytest.mark.parametrize("fuser", [True, False])
 def test_paired_forward_hoists_the_conditioning_free_prefix_exactly(fuser, monkeypatch):
     """A guidance batch [cond | uncond] carries the same latent and timestep in both halves: with ``paired=True`` the engine

@@ -7,6 +7,10 @@
 // The MFMA "A" operand is the WEIGHT tile and "B" the activation tile, so every lane ends up owning 4 consecutive
 // output columns of one output row: epilogue = 8-byte packed stores, float4 bias loads, in-register GEGLU.
 //
+// Three K-loop variants share the tile epilogue: 1 = register-staged (conv gather), 2 = LDS-DMA double buffer, 3 = LDS-DMA ring with
+// its K-tiles in flight from the first instruction (the latency kernel of the small-batch launches, round 4); the persistent
+// 256 x {320,256,128} kernel that takes every launch big enough to fill the chip is gemm_big.hip.
+//
 // Roofline: MFMA-bound (2.5 PFLOP/s dense bf16); algorithmic flops = 2*M*N*K.
 #include "gemm_core.h"
 #include "attn_core.h"
@@ -715,7 +719,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // prefetch (1) for the conv gather.  A third variant (4-stage ring of 32-deep K-steps, 3 DMA steps in flight, counted
 // vmcnt + raw s_barrier) was built and measured SLOWER than variant 2 on every shape but one (744 vs 846 TF at 8192^3,
 // 485 vs 644 at K=1280: a barrier per 8 MFMAs costs more than the deeper prefetch buys) and was removed; numbers in
-// profiles/r01_diag_B18_gemm_ring_vs_dma.log.
+// profiles/r01_diag_B18_gemm_ring_vs_dma.log.  That was THROUGHPUT on grids of thousands of tiles, two workgroups per CU; the
+// latency kernel above (round 4: 64-deep K-steps, one barrier per 16 MFMAs, one workgroup per CU) serves the opposite regime --
+// grids of <= 256 tiles, where a launch is a chain of dependent trips to memory -- and is chosen by tile count in launch().
 std::atomic<long long> idf_stat_ring_launches{0};     // launches of the latency kernel (idf_get_stat)
 int g_big_mode = -2;
 inline int gemm_big_mode() {

@@ -136,11 +136,15 @@ def test_stale_tuning_values_in_the_environment_fall_back_to_the_default():
     import subprocess
     import sys
     code = ("import instancediffusion_amd._lib as L; lib = L.load(); a = lib.idf_set_tuning(1, 1); b = lib.idf_set_tuning(0, 1); "
-            "print(a, b)")
-    env = dict(os.environ, IDF_ATTN2="9", IDF_GEMM_BIG="-5")
+            "c = lib.idf_set_tuning(L.IDF_TUNE_GEMM_RING, 256); d = lib.idf_set_tuning(L.IDF_TUNE_BIG_MIN_EFF, 50); print(a, b, c, d)")
+    env = dict(os.environ, IDF_ATTN2="9", IDF_GEMM_BIG="-5", IDF_GEMM_RING="-3", IDF_BIG_MIN_EFF="250")
     out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-500:]
-    assert out.stdout.strip().splitlines()[-1] == "1 1", out.stdout
+    assert out.stdout.strip().splitlines()[-1] == "1 1 256 50", out.stdout        # the library defaults
+    # in-range values ARE taken from the environment
+    env = dict(os.environ, IDF_GEMM_RING="0", IDF_BIG_MIN_EFF="80")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].split()[2:] == ["0", "80"], out.stdout + out.stderr[-300:]
 
 
 def test_schema_matches_reference():

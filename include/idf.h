@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IDF_ABI_VERSION 4
+#define IDF_ABI_VERSION 5
 
 enum { IDF_BF16 = 0, IDF_F16 = 1 };                 /* 16-bit storage / MFMA input type */
 enum { IDF_E_ARG = -1, IDF_E_ALIGN = -2, IDF_E_UNSUPPORTED = -3 };
@@ -77,11 +77,16 @@ const char* idf_build_info(void);
  *   kernel takes a launch whose tile grid fills at least this share of the workgroup slots of its last round.  Initial value:
  *   env IDF_BIG_MIN_EFF or the library default.
  * (ABI 2 also exposed the kernel variants that were measured slower -- GEMM geometries 1..6, attention modes 1..14; they
- * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.) */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3 };
+ * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.)
+ *   IDF_TUNE_ATTN8 (round 5, ABI 5): the d = 80 / d = 160 self and gated self-attention (n0 % 8 == n1 % 8 == 0, no mask) on the
+ *   LDS-DMA kernel of attention8.hip (32 queries per wave, K / V^T rings, deferred-rescale running max, XCD-aware 1-D grid):
+ *   0 = off (the register-staged 32-query kernel), 1 = on (d = 80: two 4-wave workgroups per CU; d = 160: one 8-wave workgroup
+ *   per 256 queries), 2 = 8-wave workgroups at d = 80 too, 3 = mode 1 with the plain block order, 4 = d = 160 on 4-wave
+ *   workgroups.  Initial value: env IDF_ATTN8 or the default (1). */
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
-enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2 };
+enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2, IDF_STAT_ATTN8_LAUNCHES = 3 };
 long long idf_get_stat(int stat);
 
 /* ---- GEMM: out[M,N] = epi( A[M,K] . W[N,K]^T ) ----------------------------------------------------------

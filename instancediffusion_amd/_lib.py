@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDF_LIB_PATH", os.path.join(_HERE, "libidf_gfx950.so"))   # override: A/B builds only
 
 IDF_BF16, IDF_F16 = 0, 1
-IDF_STAT_GEMM_BIG_LAUNCHES, IDF_STAT_ATTN2_LAUNCHES, IDF_STAT_GEMM_RING_LAUNCHES = 0, 1, 2        # idf_get_stat
-IDF_TUNE_GEMM_BIG, IDF_TUNE_ATTN2, IDF_TUNE_GEMM_RING, IDF_TUNE_BIG_MIN_EFF = 0, 1, 2, 3      # idf_set_tuning
+IDF_STAT_GEMM_BIG_LAUNCHES, IDF_STAT_ATTN2_LAUNCHES, IDF_STAT_GEMM_RING_LAUNCHES, IDF_STAT_ATTN8_LAUNCHES = 0, 1, 2, 3   # idf_get_stat
+IDF_TUNE_GEMM_BIG, IDF_TUNE_ATTN2, IDF_TUNE_GEMM_RING, IDF_TUNE_BIG_MIN_EFF, IDF_TUNE_ATTN8 = 0, 1, 2, 3, 4      # idf_set_tuning
 EPI_LN_ROW, EPI_LN_COL, EPI_GEGLU_P32 = 512, 1024, 2048
 EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \
     1, 2, 4, 8, 16, 32, 64, 128, 256
@@ -107,7 +107,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.idf_abi_version() != 4:
+    if lib.idf_abi_version() != 5:
         raise RuntimeError("libidf_gfx950.so ABI version mismatch")
     _lib = lib
     return lib

@@ -436,6 +436,10 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
     const int rc = idf_launch_attn4(p, a->B, a->dtype, s);
     if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }
   }
+  if (!a->qbits) {
+    const int rc = idf_launch_attn8(p, a->B, a->dtype, s);
+    if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn8_launches; return rc; }
+  }
   if (a->dtype == IDF_BF16) return launch_attn<IDF_BF16>(p, a->B, s);
   if (a->dtype == IDF_F16) return launch_attn<IDF_F16>(p, a->B, s);
   return IDF_E_UNSUPPORTED;

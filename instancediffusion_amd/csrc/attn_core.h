@@ -39,3 +39,15 @@ extern std::atomic<long long> idf_stat_attn2_launches;   // process-global launc
 int idf_attn2_mode();
 int idf_attn2_set_mode(int v);
 int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
+// 32-queries-per-wave LDS-DMA kernel for d in {80, 160} (attention8.hip, round 5): K / V^T rings by LDS-DMA, deferred-rescale
+// running max, XCD-aware 1-D grid.  Mode (idf_set_tuning(IDF_TUNE_ATTN8), env IDF_ATTN8): 0 = off (attention.hip's register-staged
+// kernel); 1 = on (d = 80: two 4-wave workgroups per CU, d = 160: one 8-wave workgroup per 256 queries); 2 = 8-wave workgroups
+// at d = 80 too; 3 = mode 1 with the plain block order; 4 = d = 160 on 4-wave workgroups.  Returns IDF_ATTN2_UNSUPPORTED when
+// the shape does not qualify.
+#ifndef IDF_ATTN8_DEFAULT
+#define IDF_ATTN8_DEFAULT 1
+#endif
+extern std::atomic<long long> idf_stat_attn8_launches;
+int idf_attn8_mode();
+int idf_attn8_set_mode(int v);
+int idf_launch_attn8(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);

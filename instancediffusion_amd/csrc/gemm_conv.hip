@@ -947,6 +947,10 @@ extern "C" int idf_set_tuning(int knob, int value) {
     if (value < 0 || value > 3) return IDF_E_ARG;
     return idf_attn2_set_mode(value);
   }
+  if (knob == IDF_TUNE_ATTN8) {
+    if (value < 0 || value > 4) return IDF_E_ARG;
+    return idf_attn8_set_mode(value);
+  }
   return IDF_E_ARG;
 }
 
@@ -954,6 +958,7 @@ extern "C" long long idf_get_stat(int stat) {
   if (stat == IDF_STAT_GEMM_BIG_LAUNCHES) return idf_stat_big_launches.load();
   if (stat == IDF_STAT_ATTN2_LAUNCHES) return idf_stat_attn2_launches.load();
   if (stat == IDF_STAT_GEMM_RING_LAUNCHES) return idf_stat_ring_launches.load();
+  if (stat == IDF_STAT_ATTN8_LAUNCHES) return idf_stat_attn8_launches.load();
   return -1;
 }
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libidf_gfx950.so does not export {name}"
         assert name in _lib.SYMBOLS, f"_lib.SYMBOLS has no prototype for {name}"
-    assert lib.idf_abi_version() == 4
+    assert lib.idf_abi_version() == 5
     assert b"gfx950" in lib.idf_build_info()
 
 

@@ -16,12 +16,57 @@
 #include <string>
 #include "idf.h"
 
+__device__ int g_f16 = 0;                                                     // element type of every buffer: 0 bf16, 1 fp16
+__device__ __forceinline__ float ld16(const unsigned short* p) {
+  return g_f16 ? (float)__builtin_bit_cast(_Float16, *p) : __uint_as_float(((unsigned)*p) << 16);
+}
 __global__ void fill_kernel(unsigned short* x, size_t n, unsigned seed, float scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u + seed;
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     const float f = (((h >> 8) & 0xffff) / 65536.0f - 0.5f) * scale;
-    x[i] = (unsigned short)(__float_as_uint(f) >> 16);                      // bf16 by truncation
+    x[i] = g_f16 ? __builtin_bit_cast(unsigned short, (_Float16)f) : (unsigned short)(__float_as_uint(f) >> 16);   // bf16 by truncation
+  }
+}
+// fp32 reference of ONE (batch, head, query) per block, straight from the idf_attn_args layout; err[0] = max |out - ref|,
+// err[1] = sum (out - ref)^2, err[2] = sum ref^2 (atomics on floats: a checker, not a benchmark)
+__global__ void ref_kernel(idf_attn_args a, int nsample, float* err) {
+  extern __shared__ float sc[];                    // n0 + n1 scores, then 256 reduction slots
+  const int smp = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int b = (int)(((long long)smp * 7919) % a.B), q = (int)(((long long)smp * 104729 + 17) % a.nq);
+  const int d = a.d, ntot = a.n0 + a.n1, tid = threadIdx.x;
+  float* red = sc + ntot;
+  const unsigned short* qp = (const unsigned short*)a.q + (size_t)b * a.strideQ + (size_t)q * a.ldq + h * d;
+  float mx = -INFINITY;
+  for (int j = tid; j < ntot; j += blockDim.x) {
+    const unsigned short* kp = j < a.n0 ? (const unsigned short*)a.k0 + (size_t)b * a.strideK0 + (size_t)j * a.ldk0 + h * d
+                                        : (const unsigned short*)a.k1 + (size_t)b * a.strideK1 + (size_t)(j - a.n0) * a.ldk1 + h * d;
+    float acc = 0.f;
+    for (int e = 0; e < d; ++e) acc += ld16(qp + e) * ld16(kp + e);
+    acc *= a.scale;
+    sc[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  red[tid] = mx; __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+  mx = red[0]; __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < ntot; j += blockDim.x) { const float pj = __expf(sc[j] - mx); sc[j] = pj; sum += pj; }
+  red[tid] = sum; __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  sum = red[0]; __syncthreads();
+  for (int e = tid; e < d; e += blockDim.x) {
+    const unsigned short* v0 = (const unsigned short*)a.vt0 + (size_t)b * a.strideV0 + (size_t)(h * d + e) * a.ldv0;
+    const unsigned short* v1 = a.n1 ? (const unsigned short*)a.vt1 + (size_t)b * a.strideV1 + (size_t)(h * d + e) * a.ldv1 : v0;
+    float acc = 0.f;
+    for (int j = 0; j < a.n0; ++j) acc += sc[j] * ld16(v0 + j);
+    for (int j = 0; j < a.n1; ++j) acc += sc[a.n0 + j] * ld16(v1 + j);
+    const float ref = acc / sum;
+    const float got = ld16((const unsigned short*)a.out + (size_t)b * a.strideO + (size_t)q * a.ldo + h * d + e);
+    const float df = fabsf(got - ref);
+    atomicMax((int*)&err[0], __float_as_int(df));        // non-negative floats order like ints
+    atomicAdd(&err[1], df * df);
+    atomicAdd(&err[2], ref * ref);
   }
 }
 __global__ void checksum_kernel(const unsigned* x, size_t n, unsigned long long* out) {
@@ -40,11 +85,26 @@ struct Lib {
 
 struct Shape { const char* name; int N, d, n0, n1; };
 
+static std::vector<int> int_list(const char* m) {
+  std::vector<int> v; std::string t = m; size_t p = 0;
+  while (p < t.size()) { v.push_back(atoi(t.c_str() + p)); p = t.find(',', p); if (p == std::string::npos) break; ++p; }
+  return v;
+}
+
+// Environment: HARNESS_DTYPE=f16 (default bf16), HARNESS_SCALE=<float> (amplitude of the random q / k: 1 gives near-uniform
+// softmax rows, ~5 gives rows whose maximum keeps growing over the key range -- the re-base / rescale paths), HARNESS_ATTN8=
+// list of IDF_TUNE_ATTN8 modes for the d = 80 / 160 shapes (default 0,1,2,3,4), HARNESS_SHAPES=substring filter,
+// HARNESS_REPS=launches per timing (10).
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: attn_harness lib.so [batch] [modes] [more libs]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: attn_harness lib.so [batch] [attn2 modes] [more libs]\n"); return 2; }
   const int B = argc > 2 ? atoi(argv[2]) : 64;
-  std::vector<int> modes;
-  { std::string m = argc > 3 ? argv[3] : "1,2,0"; size_t p = 0; while (p < m.size()) { modes.push_back(atoi(m.c_str() + p)); p = m.find(',', p); if (p == std::string::npos) break; ++p; } }
+  const std::vector<int> modes2 = int_list(argc > 3 ? argv[3] : "1,2,0");
+  const std::vector<int> modes8 = int_list(getenv("HARNESS_ATTN8") ? getenv("HARNESS_ATTN8") : "0,1,2,3,4");
+  const int f16 = getenv("HARNESS_DTYPE") && !strcmp(getenv("HARNESS_DTYPE"), "f16");
+  const float qscale = getenv("HARNESS_SCALE") ? (float)atof(getenv("HARNESS_SCALE")) : 1.0f;
+  const char* filt = getenv("HARNESS_SHAPES");
+  const int reps = getenv("HARNESS_REPS") ? atoi(getenv("HARNESS_REPS")) : 10;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_f16), &f16, sizeof(int));
   std::vector<Lib> libs;
   for (int i = 1; i < argc; ++i) {
     if (i == 2 || i == 3) continue;
@@ -56,58 +116,72 @@ int main(int argc, char** argv) {
     if (!l.attention || !l.set_tuning) { fprintf(stderr, "%s: missing symbols\n", argv[i]); return 2; }
     libs.push_back(l);
   }
+  printf("batch %d  dtype %s  q/k amplitude %.2f\n", B, f16 ? "f16" : "bf16", qscale);
   const int H = 8;
-  const Shape shapes[] = {{"self 64^2", 4096, 40, 4096, 0},   {"gated 64^2", 4096, 40, 4096, 184}, {"gated 32^2", 1024, 80, 1024, 184},
-                          {"gated 16^2", 256, 160, 256, 184}, {"cross 64^2", 4096, 40, 77, 0},      {"cross 32^2", 1024, 80, 77, 0}};
+  const Shape shapes[] = {{"self 64^2", 4096, 40, 4096, 0},   {"gated 64^2", 4096, 40, 4096, 184}, {"self 32^2", 1024, 80, 1024, 0},
+                          {"gated 32^2", 1024, 80, 1024, 184}, {"self 16^2", 256, 160, 256, 0},     {"gated 16^2", 256, 160, 256, 184},
+                          {"self 8^2", 64, 160, 64, 0},        {"gated 8^2", 64, 160, 64, 184},
+                          {"cross 64^2", 4096, 40, 77, 0},     {"cross 32^2", 1024, 80, 77, 0},     {"cross 16^2", 256, 160, 77, 0}};
   const size_t maxC = 1280, maxTok = (size_t)B * 4096;
   unsigned short *qk, *vt, *k1, *vt1, *kc, *vtc, *o;
   unsigned long long* csum;
+  float* err;
   hipMalloc(&qk, maxTok * 640 * 2); hipMalloc(&vt, maxTok * 320 * 2); hipMalloc(&o, maxTok * 320 * 2);
   hipMalloc(&k1, (size_t)B * 184 * maxC * 2); hipMalloc(&vt1, (size_t)B * maxC * 192 * 2);
-  hipMalloc(&kc, (size_t)B * 77 * maxC * 2); hipMalloc(&vtc, (size_t)B * maxC * 128 * 2); hipMalloc(&csum, 8);
-  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, qk, maxTok * 640, 1u, 1.0f);
+  hipMalloc(&kc, (size_t)B * 77 * maxC * 2); hipMalloc(&vtc, (size_t)B * maxC * 128 * 2); hipMalloc(&csum, 8); hipMalloc(&err, 12);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, qk, maxTok * 640, 1u, qscale);
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, vt, maxTok * 320, 2u, 1.0f);
-  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, k1, (size_t)B * 184 * maxC, 3u, 1.0f);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, k1, (size_t)B * 184 * maxC, 3u, qscale);
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, vt1, (size_t)B * maxC * 192, 4u, 1.0f);
-  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, kc, (size_t)B * 77 * maxC, 5u, 1.0f);
-  hipMemset(vtc, 0, (size_t)B * maxC * 128 * 2);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, kc, (size_t)B * 77 * maxC, 5u, qscale);
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, vtc, (size_t)B * maxC * 128, 6u, 1.0f);   // (pad columns beyond 77 are never read)
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (const Shape& sh : shapes) {
+    if (filt && !strstr(sh.name, filt)) continue;
     const int C = H * sh.d, N = sh.N;
     idf_attn_args a; memset(&a, 0, sizeof(a));
     a.q = qk; a.ldq = 2 * C; a.strideQ = (long long)N * 2 * C; a.nq = N;
     if (sh.n0 == 77) {
       a.k0 = kc; a.ldk0 = C; a.strideK0 = 77LL * C; a.vt0 = vtc; a.ldv0 = 128; a.strideV0 = (long long)C * 128; a.n0 = 77;
-    } else {
+    } else if (N >= 1024) {
       a.k0 = qk + C; a.ldk0 = 2 * C; a.strideK0 = (long long)N * 2 * C;
       a.vt0 = vt; a.ldv0 = B * N; a.strideV0 = N; a.n0 = N;                    // V^T[c][b][token]: sample b through base + b N, ld = B N
+    } else {
+      a.k0 = qk + C; a.ldk0 = 2 * C; a.strideK0 = (long long)N * 2 * C;
+      a.vt0 = vt; a.ldv0 = (N + 63) / 64 * 64; a.strideV0 = (long long)C * a.ldv0; a.n0 = N;   // V^T[b][c][token] (the engine's layout below 1024 tokens)
     }
     if (sh.n1) { a.k1 = k1; a.ldk1 = C; a.strideK1 = 184LL * C; a.vt1 = vt1; a.ldv1 = 192; a.strideV1 = (long long)C * 192; a.n1 = 184; }
     a.out = o; a.ldo = C; a.strideO = (long long)N * C;
-    a.B = B; a.H = H; a.d = sh.d; a.scale = 1.0f / sqrtf((float)sh.d); a.dtype = IDF_BF16;
+    a.B = B; a.H = H; a.d = sh.d; a.scale = 1.0f / sqrtf((float)sh.d); a.dtype = f16 ? IDF_F16 : IDF_BF16;
     const double flops = 4.0 * B * (double)N * (sh.n0 + sh.n1) * C;
     for (int w = 0; w < 3; ++w) libs[0].attention(&a, nullptr);               // clock / cache warm-up
+    const bool v8 = (sh.d == 80 || sh.d == 160) && sh.n0 != 77;
+    const std::vector<int>& modes = v8 ? modes8 : modes2;
+    const int knob = v8 ? 4 /* IDF_TUNE_ATTN8 */ : IDF_TUNE_ATTN2;
     for (size_t li = 0; li < libs.size(); ++li)
       for (int m : modes) {
-        if (libs[li].set_tuning(IDF_TUNE_ATTN2, m) < 0) continue;
+        if (libs[li].set_tuning(knob, m) < 0) continue;
         double best = 1e30;
         int rc = 0;
         for (int rep = 0; rep < 3; ++rep) {
           rc |= libs[li].attention(&a, nullptr);
           hipEventRecord(e0, 0);
-          for (int i = 0; i < 10; ++i) rc |= libs[li].attention(&a, nullptr);
+          for (int i = 0; i < reps; ++i) rc |= libs[li].attention(&a, nullptr);
           hipEventRecord(e1, 0);
           hipDeviceSynchronize();
           float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-          if (ms / 10 < best) best = ms / 10;
+          if (ms / reps < best) best = ms / reps;
         }
         hipMemsetAsync(csum, 0, 8, 0);
+        hipMemsetAsync(err, 0, 12, 0);
         hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const unsigned*>(o), (size_t)B * N * C / 2, csum);
+        const int nsample = 24;
+        hipLaunchKernelGGL(ref_kernel, dim3(nsample * H), dim3(256), (sh.n0 + sh.n1 + 256) * sizeof(float), 0, a, nsample, err);
         unsigned long long cs = 0; hipMemcpy(&cs, csum, 8, hipMemcpyDeviceToHost);
-        printf("%-12s d=%-3d keys %4d+%-3d  lib %zu mode %d: rc %d  %8.1f us  %7.1f TF  checksum %016llx\n", sh.name, sh.d, sh.n0, sh.n1, li, m, rc,
-               best * 1e3, flops / (best * 1e-3) / 1e12, cs);
+        float er[3]; hipMemcpy(er, err, 12, hipMemcpyDeviceToHost);
+        printf("%-11s d=%-3d keys %4d+%-3d lib %zu knob %d mode %d: rc %d %8.1f us %7.1f TF  csum %016llx  maxerr %.2e relrms %.2e\n", sh.name, sh.d,
+               sh.n0, sh.n1, li, knob, m, rc, best * 1e3, flops / (best * 1e-3) / 1e12, cs, er[0], sqrt(er[1] / (er[2] + 1e-30)));
         if (libs[li].trace_read && sh.d == 40 && sh.n0 > 77 && m >= 1) {
           unsigned long long tr[2][10];
           if (libs[li].trace_read(&tr[0][0]) == 0) {
@@ -122,7 +196,7 @@ int main(int argc, char** argv) {
             }
           }
         }
-        libs[li].set_tuning(IDF_TUNE_ATTN2, 1);
+        libs[li].set_tuning(knob, 1);
       }
   }
   return 0;

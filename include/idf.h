@@ -81,8 +81,9 @@ const char* idf_build_info(void);
  *   IDF_TUNE_ATTN8 (round 5, ABI 5): the d = 80 / d = 160 self and gated self-attention (n0 % 8 == n1 % 8 == 0, no mask) on the
  *   LDS-DMA kernel of attention8.hip (32 queries per wave, K / V^T rings, deferred-rescale running max, XCD-aware 1-D grid):
  *   0 = off (the register-staged 32-query kernel), 1 = on (d = 80: two 4-wave workgroups per CU; d = 160: one 8-wave workgroup
- *   per 256 queries), 2 = 8-wave workgroups at d = 80 too, 3 = mode 1 with the plain block order, 4 = d = 160 on 4-wave
- *   workgroups.  Initial value: env IDF_ATTN8 or the default (1). */
+ *   per 256 queries, 4-wave workgroups below), 2 = 8-wave workgroups throughout, 3 = mode 1 with the plain block order,
+ *   4 = d = 160 on 4-wave workgroups, 5 / 6 = d = 80 software-pipelined on 4- / 8-wave workgroups.
+ *   Initial value: env IDF_ATTN8 or the default (1). */
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */

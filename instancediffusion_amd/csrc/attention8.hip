@@ -62,7 +62,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   return r;
 }
 
-template <int DT, int D, int NW, bool KPRE>
+template <int DT, int D, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, const int nqb, const int xcd_order) {
   static_assert(D % 16 == 0, "head dim must fill whole K-steps");
   constexpr int NKS = D / 16;                      // K-steps of K.Q^T
@@ -73,7 +73,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
   constexpr int KSZ = KVT * KCH * 8;               // K stage (elements)
   constexpr int VROWS = NMT * 32;
   constexpr int VSZ = VROWS * KVT;                 // V^T stage (elements)
-  constexpr int KST = KPRE ? 3 : 2, KA = KST - 1;  // K ring stages; K is fetched KA tiles ahead, V^T one tile ahead
+  // MODE 0: K fragments of tile t+1 read into registers under the P.V MFMAs of tile t (3-stage K ring); 1: no look-ahead, K fragments
+  // read inside the K.Q^T loop (2-stage ring); 2: software-pipelined -- K.Q^T of tile t+1 is issued BEFORE the softmax of tile t
+  // (two score blocks live, 3-stage ring), so every wave carries an MFMA stream that does not depend on its own exponentials
+  constexpr bool KPRE = MODE == 0, PIPE = MODE == 2;
+  constexpr int KST = MODE == 1 ? 2 : 3, KA = KST - 1;  // K ring stages; K is fetched KA tiles ahead, V^T one tile ahead
   constexpr int K_INST = KCH, V_INST = DCH;        // LDS-DMA instructions per K / V^T tile (64 slots = 1 KiB each)
   constexpr int N_INST = K_INST + V_INST;
   constexpr int PER_WAVE = (N_INST + NW - 1) / NW;
@@ -108,21 +112,35 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
     for (int i = tid; i < 2 * KVT; i += NT) Vs[(i / KVT) * VSZ + D * KVT + (i % KVT)] = one;      // swizzle-invariant: a whole row
   }
 
-  // ---- Q fragments (B operand), pre-multiplied by scale*log2(e): lane holds q = l31, e = 16 ks + 8 hi .. +7
+  // ---- Q fragments (B operand): lane holds q = l31, e = 16 ks + 8 hi .. +7, pre-multiplied by scale*log2(e) (as attention4.hip and
+  // torch's math SDPA do).  -DIDF_ATTN8_FMA_SCALE keeps Q raw and scales in the exponent's fma instead (p = 2^(s c - m)): one
+  // rounding of Q fewer -- rel-RMS 2.0e-3 instead of 3.4e-3 against the fp32 reference on wide score distributions, equal on
+  // narrow ones -- but the 32 v_fma_f32 (VOP3, SGPR or VGPR scale alike) per tile in place of 32 v_sub_f32 cost 5-14 % of the
+  // kernel on every box measured (profiles/r05_attn8_third.log, r05_attn8_fourth.log), so the default pre-multiplies.
   u32x4 qf[NKS];
   {
     const int qr = min(qb * (NW * 32) + wave * 32 + l31, p.nq - 1);
     const unsigned short* qp = p.q + (size_t)b * p.sQ + (size_t)qr * p.ldq + h * D;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16 + hi * 8);
+      qf[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16 + hi * 8);
+#ifndef IDF_ATTN8_FMA_SCALE
       float f[8];
-      unpack8<DT>(v, f);
+      unpack8<DT>(qf[ks], f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2;
       qf[ks] = pack8<DT>(f);
+#endif
     }
   }
+#ifndef IDF_ATTN8_FMA_SCALE
+  const float c = 1.0f;
+#else
+  float c = p.scale_log2;
+#ifdef IDF_ATTN8_CVGPR
+  asm volatile("" : "+v"(c));
+#endif
+#endif
 
   const int T0 = (p.n[0] + KVT - 1) / KVT;
   const int T1 = (p.n[1] + KVT - 1) / KVT;
@@ -229,9 +247,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
     }
   };
 
-  f32x16 s[2];
   u32x4 pk[4];
-  auto qk = [&](const int stage) {
+  auto qk = [&](f32x16 (&s)[2], const int stage) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (KPRE) {
 #pragma unroll
@@ -253,11 +270,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
     return fmaxf(mx, __uint_as_float(hi ? sw[0] : sw[1]));
   };
-  auto exp_pack = [&](const int st) {                // P = 2^(s - m) of one 32-key half, packed; !MFMASUM: row sum
+  float neg_m = INFINITY;                            // -m_run (log2 units, scaled)
+  auto exp_pack = [&](f32x16 (&s)[2], const int st) {      // P = 2^(s c - m) of one 32-key half, packed; !MFMASUM: row sum
     float rs = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[st][r] = __builtin_amdgcn_exp2f(s[st][r] - m_run);
+#ifndef IDF_ATTN8_FMA_SCALE
+      s[st][r] = __builtin_amdgcn_exp2f(s[st][r] + neg_m);
+#else
+      s[st][r] = __builtin_amdgcn_exp2f(fmaf(s[st][r], c, neg_m));
+#endif
       if constexpr (!MFMASUM) rs += s[st][r];
     }
     if constexpr (!MFMASUM) l_run += rs;
@@ -283,8 +305,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
       for (int mt = 0; mt < NMT; ++mt) o[mt] = Elem<DT>::mfma32(a[k2][mt], pk[st * 2 + k2], o[mt]);
     }
   };
-  auto tile = [&](const int t) {
-    qk(t % KST);
+  // tile t's scores (in s): tail mask, maximum, (rare) rescale of O -- everything in front of the exponentials
+  auto decide = [&](f32x16 (&s)[2], const int t) {
     // tail tile (wave-uniform, rare): invalid keys -> -inf (their K rows are clamped duplicates: finite scores)
     {
       const int seg = (t < T0) ? 0 : 1;
@@ -309,20 +331,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
     }
     m0 = max3f(m0, m1, s[0][15]);
     m0 = max3f(m0, m0, s[1][15]);
-    const float mx = half_max(m0);
+    const float mx = half_max(m0) * c;               // c > 0
     if (__builtin_amdgcn_ballot_w64(mx > m_run + DEFER) != 0) {       // first tile: m_run = -inf -> always
       const float m_new = fmaxf(m_run, mx);
       const float al = __builtin_amdgcn_exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile (O = l = 0 anyway)
       m_run = m_new;
+      neg_m = -m_new;
       l_run *= al;
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mt][r] *= al;
     }
-    exp_pack(0);
+  };
+  // exponentials of tile t and its P.V (one basic block; PIPE: together with the K.Q^T MFMAs of tile t+1 issued in front of it)
+  auto exp_pv = [&](f32x16 (&s)[2], const int t) {
+    exp_pack(s, 0);
     pv(0, t & 1);
-    exp_pack(1);
+    exp_pack(s, 1);
     if constexpr (KPRE) load_kf((t + 1) % KST);      // next tile's K fragments (a stale stage after the last tile: unused)
     pv(1, t & 1);
     if constexpr (KPRE) {
@@ -336,16 +362,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-
-  __syncthreads();                                  // pad rows / ones row complete
-  issue_cold(0, true, true);
-  if (KPRE && T > 1) issue_cold(1, true, false);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  load_kf(0);
-  for (int t = 0; t < T; ++t) {
-    // Every wave passed the barrier that ended tile t-1: K(t) [KPRE: and K(t+1)] and V^T(t) are visible; the stages of
-    // K(t+KA) and V^T(t+1) were last read in tile t-1.
+  // top of tile t.  Every wave passed the barrier that ended tile t-1: K(t) [3-stage ring: and K(t+1)] and V^T(t) are visible;
+  // the stages of K(t+KA) and V^T(t+1) were last read in tile t-1 or earlier.
+  auto issue = [&](const int t) {
     const int tk = t + KA, tv = t + 1;
     if (tk < F0) {                                   // (tv <= tk): both are full tiles of segment 0
       issue_hot(tk, tv);
@@ -353,8 +372,39 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
       if (tk < T) issue_cold(tk, true, false);
       if (tv < T) issue_cold(tv, false, true);
     }
-    tile(t);
-    end_tile();
+  };
+
+  __syncthreads();                                  // pad rows / ones row complete
+  issue_cold(0, true, true);
+  if (KST == 3 && T > 1) issue_cold(1, true, false);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if constexpr (PIPE) {
+    f32x16 sA[2], sB[2];
+    qk(sA, 0);
+    for (int t = 0; t < T; t += 2) {
+      issue(t);
+      decide(sA, t);
+      qk(sB, (t + 1) % KST);                         // (behind the last tile: a stale stage, result unused)
+      exp_pv(sA, t);
+      end_tile();
+      if (t + 1 >= T) break;
+      issue(t + 1);
+      decide(sB, t + 1);
+      qk(sA, (t + 2) % KST);
+      exp_pv(sB, t + 1);
+      end_tile();
+    }
+  } else {
+    f32x16 s[2];
+    load_kf(0);
+    for (int t = 0; t < T; ++t) {
+      issue(t);
+      qk(s, t % KST);
+      decide(s, t);
+      exp_pv(s, t);
+      end_tile();
+    }
   }
 
   // ---- normalise and store.  o[mt][r]: e = mt*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31.
@@ -403,15 +453,15 @@ int set_lds_attr(K kern, int bytes) {
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int DT, int D, int NW, bool KPRE>
+template <int DT, int D, int NW, int MODE>
 int launch_one(const AttnParams& p, int B, int order, hipStream_t s) {
   constexpr int NMT = (D + 31) / 32, KCH = (D / 8) | 1;
-  constexpr int LDS = ((KPRE ? 3 : 2) * KVT * KCH * 8 + 2 * NMT * 32 * KVT) * 2;
-  auto kern = attn8_kernel<DT, D, NW, KPRE>;
+  constexpr int LDS = ((MODE == 1 ? 2 : 3) * KVT * KCH * 8 + 2 * NMT * 32 * KVT) * 2;
+  auto kern = attn8_kernel<DT, D, NW, MODE>;
   if (LDS > 48 * 1024) {
     static bool done[64] = {};
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !done[dev]) {
       if (set_lds_attr(kern, LDS) != 0) return IDF_E_UNSUPPORTED;
       if (dev >= 0 && dev < 64) done[dev] = true;
@@ -424,11 +474,19 @@ int launch_one(const AttnParams& p, int B, int order, hipStream_t s) {
 
 template <int DT>
 int launch_attn8(const AttnParams& p, int B, int mode, hipStream_t s) {
-  // mode 1: automatic (d = 80: 4-wave workgroups, two per CU; d = 160: one 8-wave workgroup per 256 queries), XCD-aware;
-  // 2: 8-wave workgroups for d = 80 too; 3: mode 1 with the plain block order; 4: d = 160 on 4-wave workgroups
+  // mode 1: default (d = 80: two 4-wave workgroups per CU, K fragments one tile ahead; d = 160: 8-wave workgroups from 256
+  // queries, 4-wave below); 2..6: A/B variants (tools/ubench/attn_harness.hip, profiles/r05_attn8_*.log)
   const int order = mode == 3 ? 0 : 1;
-  if (p.d == 80) return mode == 2 ? launch_one<DT, 80, 8, true>(p, B, order, s) : launch_one<DT, 80, 4, true>(p, B, order, s);
-  if (p.d == 160) return mode == 4 ? launch_one<DT, 160, 4, false>(p, B, order, s) : launch_one<DT, 160, 8, false>(p, B, order, s);
+  if (p.d == 80) {
+    if (mode == 2) return launch_one<DT, 80, 8, 0>(p, B, order, s);
+    if (mode == 5) return launch_one<DT, 80, 4, 2>(p, B, order, s);
+    if (mode == 6) return launch_one<DT, 80, 8, 2>(p, B, order, s);
+    return launch_one<DT, 80, 4, 0>(p, B, order, s);
+  }
+  if (p.d == 160) {
+    if (mode == 4 || (mode != 2 && p.nq < 256)) return launch_one<DT, 160, 4, 1>(p, B, order, s);
+    return launch_one<DT, 160, 8, 1>(p, B, order, s);
+  }
   return IDF_ATTN2_UNSUPPORTED;
 }
 
@@ -441,7 +499,7 @@ int idf_attn8_mode() {
   if (g_attn8_mode == -2) {
     const char* e = getenv("IDF_ATTN8");
     const int v = e ? atoi(e) : IDF_ATTN8_DEFAULT;
-    g_attn8_mode = (v < 0 || v > 4) ? IDF_ATTN8_DEFAULT : v;
+    g_attn8_mode = (v < 0 || v > 6) ? IDF_ATTN8_DEFAULT : v;
   }
   return g_attn8_mode;
 }

@@ -41,9 +41,10 @@ int idf_attn2_set_mode(int v);
 int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
 // 32-queries-per-wave LDS-DMA kernel for d in {80, 160} (attention8.hip, round 5): K / V^T rings by LDS-DMA, deferred-rescale
 // running max, XCD-aware 1-D grid.  Mode (idf_set_tuning(IDF_TUNE_ATTN8), env IDF_ATTN8): 0 = off (attention.hip's register-staged
-// kernel); 1 = on (d = 80: two 4-wave workgroups per CU, d = 160: one 8-wave workgroup per 256 queries); 2 = 8-wave workgroups
-// at d = 80 too; 3 = mode 1 with the plain block order; 4 = d = 160 on 4-wave workgroups.  Returns IDF_ATTN2_UNSUPPORTED when
-// the shape does not qualify.
+// kernel); 1 = on (d = 80: two 4-wave workgroups per CU with the K fragments read one tile ahead; d = 160: one 8-wave workgroup
+// per 256 queries, 4-wave workgroups below 256 queries); 2 = 8-wave workgroups at d = 80 and at every d = 160 size; 3 = mode 1
+// with the plain block order; 4 = d = 160 on 4-wave workgroups; 5 / 6 = d = 80 software-pipelined (K.Q^T of tile t+1 issued in
+// front of tile t's exponentials) on 4- / 8-wave workgroups.  Returns IDF_ATTN2_UNSUPPORTED when the shape does not qualify.
 #ifndef IDF_ATTN8_DEFAULT
 #define IDF_ATTN8_DEFAULT 1
 #endif

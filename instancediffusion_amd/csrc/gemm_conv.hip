@@ -948,7 +948,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
     return idf_attn2_set_mode(value);
   }
   if (knob == IDF_TUNE_ATTN8) {
-    if (value < 0 || value > 4) return IDF_E_ARG;
+    if (value < 0 || value > 6) return IDF_E_ARG;
     return idf_attn8_set_mode(value);
   }
   return IDF_E_ARG;

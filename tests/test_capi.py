@@ -102,14 +102,19 @@ def test_argument_validation_without_gpu():
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ln_stats=0x20004)), None) == -2
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ldw2=640)), None) == -1                # rows of W2 shorter than 4C
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
-    assert lib.idf_set_tuning(4, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
+    assert lib.idf_set_tuning(5, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
+    # round 5 (ABI 5): the d = 80 / 160 LDS-DMA attention kernel's knob and launch counter
+    assert lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 7) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, -1) == -1
+    prev = lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 3)
+    assert prev in range(7) and lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, prev) == 3
+    assert lib.idf_get_stat(_lib.IDF_STAT_ATTN8_LAUNCHES) == 0
     prev = lib.idf_set_tuning(1, 2)
     assert prev in (0, 1, 2, 3) and lib.idf_set_tuning(1, prev) == 2
     # round 4: tile-count threshold of the latency kernel (0 = never), and its launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 77)
     assert prev >= 0 and lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, prev) == 77
-    assert lib.idf_get_stat(_lib.IDF_STAT_GEMM_RING_LAUNCHES) == 0 and lib.idf_get_stat(3) == -1
+    assert lib.idf_get_stat(_lib.IDF_STAT_GEMM_RING_LAUNCHES) == 0 and lib.idf_get_stat(4) == -1
     assert lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 0) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 101) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 60)
     assert 1 <= prev <= 100 and lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, prev) == 60

@@ -1250,6 +1250,121 @@ def test_attention_v4_reference_value_paths(ref, attn4, case):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the d = 80 / 160 LDS-DMA attention kernel (attention8.hip, round 5), forced through idf_set_tuning(IDF_TUNE_ATTN8)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[(1, torch.bfloat16), (1, torch.float16), (2, torch.bfloat16), (3, torch.bfloat16), (4, torch.bfloat16),
+                        (5, torch.bfloat16), (6, torch.float16)],
+                ids=["default-bf16", "default-fp16", "8waves", "plain-grid", "d160-4waves", "d80-4waves-pipelined",
+                     "d80-8waves-pipelined-fp16"])
+def attn8(request):
+    """attention8.hip in its launch variants and both storage types; yields (ops, dtype, launch counter)."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.ops import HipOps
+    lib = _lib.load()
+    mode, dt = request.param
+    prev = lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, mode)
+    start = lib.idf_get_stat(_lib.IDF_STAT_ATTN8_LAUNCHES)
+    yield HipOps(dt), dt, (lambda: lib.idf_get_stat(_lib.IDF_STAT_ATTN8_LAUNCHES) - start)
+    lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, prev)
+
+
+@pytest.mark.parametrize("B,H,d,Nq,n0,n1", [
+    (2, 8, 80, 1024, 1024, 184), (1, 8, 80, 300, 304, 184), (2, 8, 160, 256, 256, 184), (1, 8, 160, 64, 64, 184),
+    (1, 8, 160, 100, 104, 0), (2, 8, 80, 200, 72, 0), (1, 4, 80, 513, 520, 40), (3, 8, 160, 256, 256, 0), (1, 8, 80, 64, 8, 8)])
+def test_attention_v8(ref, attn8, B, H, d, Nq, n0, n1):
+    """Shapes of the 32^2 / 16^2 / 8^2 levels plus ragged query counts, key tails in either segment, a one-tile key set and
+    an 8-key one; the V^T pads are NaN (they must never reach the output) and q / k are column slices of one buffer, as the
+    engine passes them."""
+    ops, dt, count = attn8
+    C = H * d
+    nk = max(Nq, n0)
+    qk = gen((B, nk, 2 * C), 40).to(dt)
+    v0 = gen((B, n0, C), 42).to(dt)
+    ld0 = (n0 + 63) // 64 * 64
+    vt0 = torch.full((B, C, ld0), float("nan"), dtype=dt)
+    vt0[:, :, :n0] = v0.transpose(1, 2)
+    q, k0 = qk[:, :Nq, :C], qk[:, :n0, C:]
+    kw, rkw = {}, {}
+    if n1:
+        k1, v1 = gen((B, n1, C), 43).to(dt), gen((B, n1, C), 44).to(dt)
+        vt1 = torch.full((B, C, 192), float("nan"), dtype=dt)
+        vt1[:, :, :n1] = v1.transpose(1, 2)
+        kw = dict(k1=dev(k1), vt1=dev(vt1), n1=n1)
+        rkw = dict(k1=k1.float(), vt1=torch.nan_to_num(vt1.float()), n1=n1)
+    want = ref.attention(q.float(), k0.float(), torch.nan_to_num(vt0.float()), n0, torch.empty(B, Nq, C), H, **rkw)
+    dqk = dev(qk)
+    out = ops.attention(dqk[:, :Nq, :C], dqk[:, :n0, C:], dev(vt0), n0, ops.empty((B, Nq, C)), H, **kw)
+    torch.cuda.synchronize()
+    assert count() == 1, "the launch must have gone to attention8.hip"
+    assert torch.isfinite(out.float()).all()
+    tol, rms_tol = (2 * BF16_TOL, 2 * BF16_RMS_TOL) if dt == torch.bfloat16 else (2.0 ** -9, 1e-3)
+    err, mx = rel_rms(out, want), relmax(out, want)
+    print(f"[parity] attention v8 d{d} Nq{Nq} keys {n0}+{n1} {dt}: rel-rms {err:.3e} max-rel {mx:.3e}")
+    assert mx < tol and err < rms_tol
+
+
+@pytest.mark.parametrize("case", ["late-spike", "first-tile-spike", "huge-spike", "seg1-spike", "creeping-max"])
+@pytest.mark.parametrize("d", [80, 160])
+def test_attention_v8_rescale_paths(ref, attn8, case, d):
+    """The deferred rescale: O is rescaled (and the reference m raised) only when a tile maximum exceeds m by more than 2^6.
+    (a) a late spike (many tiles at alpha == 1, then one big raise), (b) a spike in the first tile (every later P underflows),
+    (c) a spike of hundreds of log2 units (no overflow with a running max: P <= 2^6 always), (d) a spike inside the tail tile of
+    segment 1, (e) a maximum that creeps up by ~3 log2 units per tile (below the threshold most tiles: P grows up to 2^6 before
+    a rescale -- the deferred path proper).  Against the fp32 reference, rel-RMS and relative to the output max."""
+    ops, dt, count = attn8
+    B, H, N, n1 = 2, 8, 640, 184
+    C = H * d
+    q, k, v = gen((B, N, C), 60), gen((B, N, C), 61), gen((B, N, C), 62)
+    k1, v1 = gen((B, n1, C), 63), gen((B, n1, C), 64)
+    if case == "late-spike":
+        k[:, 500] = q[:, 7] * 4.0
+    if case == "first-tile-spike":
+        k[:, 3] = q[:, 300] * 6.0
+    if case == "huge-spike":
+        k[:, 450] = q[:, 9] * 40.0
+    if case == "seg1-spike":
+        k1[:, 180] = q[:, 11] * 5.0
+    if case == "creeping-max":
+        for t in range(10):                              # key 64 t + 5 scores ~ 3 (t + 1) log2 units for query 21
+            k[:, 64 * t + 5] = q[:, 21] * (0.33 * (t + 1) * (80.0 / d) ** 0.5)
+    q, k, v, k1, v1 = (t.to(dt) for t in (q, k, v, k1, v1))
+    vt = torch.full((B, C, N), float("nan"), dtype=dt)
+    vt[:, :, :N] = v.transpose(1, 2)
+    vt1 = torch.full((B, C, 192), float("nan"), dtype=dt)
+    vt1[:, :, :n1] = v1.transpose(1, 2)
+    want = ref.attention(q.float(), k.float(), torch.nan_to_num(vt.float()), N, torch.empty(B, N, C), H,
+                         k1=k1.float(), vt1=torch.nan_to_num(vt1.float()), n1=n1)
+    out = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H, k1=dev(k1), vt1=dev(vt1), n1=n1)
+    torch.cuda.synchronize()
+    assert count() == 1
+    assert torch.isfinite(out.float()).all()
+    tol = BF16_TOL if dt == torch.bfloat16 else 2.0 ** -10
+    err, mx = rel_rms(out, want), relmax(out, want)
+    print(f"[parity] attention v8 d{d} {case} {dt}: rel-rms {err:.3e} max-rel {mx:.3e}")
+    assert mx < 2 * tol and err < tol
+
+
+def test_attention_v8_matches_v1(attn8):
+    """Same inputs through attention8.hip and the register-staged kernel of attention.hip: same algorithm, different summation
+    order and rescale schedule."""
+    from instancediffusion_amd import _lib
+    ops, dt, count = attn8
+    B, H, d, N = 2, 8, 80, 1024
+    C = H * d
+    q, k, v = gen((B, N, C), 50).to(dt), gen((B, N, C), 51).to(dt), gen((B, N, C), 52).to(dt)
+    vt = v.transpose(1, 2).contiguous()
+    o8 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    assert count() == 1
+    mode = _lib.load().idf_set_tuning(_lib.IDF_TUNE_ATTN8, 0)
+    o1 = ops.attention(dev(q), dev(k), dev(vt), N, ops.empty((B, N, C)), H)
+    torch.cuda.synchronize()
+    _lib.load().idf_set_tuning(_lib.IDF_TUNE_ATTN8, mode)
+    assert count() == 1
+    assert relmax(o8, o1) < (BF16_TOL if dt == torch.bfloat16 else 2.0 ** -10)
+
+
+# ---------------------------------------------------------------------------------------------------
 # full-size properties (BASELINE shapes: 64-row forward batch at the 64x64 latent): no oracle needed
 # ---------------------------------------------------------------------------------------------------
 FULL_B = 16          # rows of the property checks (the kernels see M = FULL_B * 4096 = 65536 token rows)

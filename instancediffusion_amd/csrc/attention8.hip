@@ -447,26 +447,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
   }
 }
 
-template <typename K>
-int set_lds_attr(K kern, int bytes) {
-  // the opt-in for > 64 KB of dynamic LDS is per device and per kernel: keyed by (device, kernel) -- ADVICE r4
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
 template <int DT, int D, int NW, int MODE>
 int launch_one(const AttnParams& p, int B, int order, hipStream_t s) {
   constexpr int NMT = (D + 31) / 32, KCH = (D / 8) | 1;
   constexpr int LDS = ((MODE == 1 ? 2 : 3) * KVT * KCH * 8 + 2 * NMT * 32 * KVT) * 2;
   auto kern = attn8_kernel<DT, D, NW, MODE>;
-  if (LDS > 48 * 1024) {
-    static bool done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-      if (set_lds_attr(kern, LDS) != 0) return IDF_E_UNSUPPORTED;
-      if (dev >= 0 && dev < 64) done[dev] = true;
-    }
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (idf_lds_optin(reinterpret_cast<const void*>(kern), LDS, attr_done) != 0) return IDF_E_UNSUPPORTED;
   const int nqb = (p.nq + NW * 32 - 1) / (NW * 32);
   hipLaunchKernelGGL(kern, dim3(nqb * p.H * B), dim3(NW * 64), LDS, s, p, nqb, order);
   return idf_launch_status();

@@ -110,4 +110,17 @@ static inline int idf_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+// One-time opt-in of a kernel to more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize), PER DEVICE and
+// thread-safe: `done` is the kernel's own static bit mask of devices already served (the process-wide `static bool`
+// this replaces was neither -- a second device of a multi-device process launched without the attribute).
+#include <atomic>
+static inline int idf_lds_optin(const void* kern, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev >= 0 && ((done.load(std::memory_order_relaxed) >> dev) & 1ull)) return 0;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0) done.fetch_or(1ull << dev, std::memory_order_relaxed);
+  return 0;
+}
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

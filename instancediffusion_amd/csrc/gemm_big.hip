@@ -928,12 +928,8 @@ int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   }
   void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS, GLU>;
   constexpr int smem = NSTG * (BM + BN) * BKT * 2 + NWAVES * 2048;      // ring + one 2-KB slot per wave (160 KB at BN = 320)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (const int e = idf_lds_optin(reinterpret_cast<const void*>(kern), smem, attr_done)) return e;
   CoreParams q = p;
   q.splitk = splitk; q.kt_per_slice = p.K / BKT / splitk; q.kt_full = p.K / BKT;
   const int tiles_all = (p.N / BN) * ((p.M + BM - 1) / BM);

@@ -748,12 +748,8 @@ int launch_cfg(const CoreParams& p, int batch, hipStream_t s) {
   constexpr int kloop2 = 2 * (BM + BN) * 64 * 2;
   int smem = 2 * (BM + BN) * LSTR * 2;
   if (variant == 2) { kern = gemm_kernel_dma<DT, BM, BN, WM, WN, CONV>; smem = kloop2 > cstage ? kloop2 : cstage; }
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[variant]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set[variant] = true;
-  }
+  static std::atomic<unsigned long long> attr_done[3];
+  if (const int e = idf_lds_optin(reinterpret_cast<const void*>(kern), smem, attr_done[variant])) return e;
   CoreParams q = p;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   const int nk = p.K / BK;
@@ -799,7 +795,12 @@ template <int DT, int BM, int BN, int WM, int WN, bool CONV, int NS>
 int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   const int nk = p.K / BK;
-  if (tiles > gemm_ring_tiles()) return IDF_BIG_UNSUPPORTED;
+  // the threshold counts WORKGROUPS: a batched launch multiplies the tile grid by its batch (the transposed-V GEMM of a 128-row
+  // forward: 20 tiles x 128 = 2560 workgroups of a kernel that runs one per CU on a 120-128 KB ring -- ADVICE r4); IDF_RING_BATCHED=1
+  // restores the round-4 rule (per-batch tile count) for A/B runs
+  static int batched_old = -1;
+  if (batched_old < 0) { const char* e = getenv("IDF_RING_BATCHED"); batched_old = (e && e[0] == '1') ? 1 : 0; }
+  if ((long long)tiles * (batched_old ? 1 : batch) > gemm_ring_tiles()) return IDF_BIG_UNSUPPORTED;
   const int slots = idf_num_cu();
   // a grid of 129 ... 191 tiles with a long K: variants 1 / 2 cut it into K-slices for their two workgroups per CU, this
   // kernel (one per CU) cannot -- throughput, not latency, decides there (3x3 conv 16^2 -> 32^2 at 2 rows: 105 vs 141 us)
@@ -808,12 +809,8 @@ int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
   constexpr int cstage = 4 * WM * (WN + 4) * 4;
   constexpr int kloop = NS * (BM + BN) * 64 * 2;
   constexpr int smem = kloop > cstage ? kloop : cstage;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (const int e = idf_lds_optin(reinterpret_cast<const void*>(kern), smem, attr_done)) return e;
   CoreParams q = p;
   q.splitk = 1; q.kt_per_slice = nk;
   q.tail_m0 = 0; q.tail_rows = p.M;

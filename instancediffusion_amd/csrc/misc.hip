@@ -385,13 +385,8 @@ extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bia
   if (Cin == 4 && Cout == 320 && (dtype == IDF_BF16 || dtype == IDF_F16) && aligned16(bias)) {     // the UNet's first conv: matrix cores
     const void* fn = dtype == IDF_F16 ? (const void*)conv_in_mfma_kernel<IDF_F16> : (const void*)conv_in_mfma_kernel<IDF_BF16>;
     constexpr int smem_m = (320 + 256) * CIM_KP * 2;
-    static bool attr_m[2] = {false, false};
-    const int v = dtype == IDF_F16 ? 1 : 0;
-    if (!attr_m[v]) {
-      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_m);
-      if (e != hipSuccess) return (int)e;
-      attr_m[v] = true;
-    }
+    static std::atomic<unsigned long long> attr_m[2];
+    if (const int e = idf_lds_optin(fn, smem_m, attr_m[dtype == IDF_F16 ? 1 : 0])) return e;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const long long tiles = ((long long)B * H * W + 255) / 256;
@@ -405,14 +400,9 @@ extern "C" int idf_conv_in(const float* x_nchw, const float* w, const float* bia
   const size_t smem = (size_t)9 * Cin * Cout * sizeof(float);
   if (smem > 144 * 1024) return IDF_E_UNSUPPORTED;               // gfx950: 160 KB LDS per CU
   if (smem > 64 * 1024) {                                        // e.g. the VAE decoder's 4 -> 512 first conv (72 KB)
-    static bool attr_set[2] = {false, false};
-    const int v = dtype == IDF_F16 ? 1 : 0;
-    if (!attr_set[v]) {
-      const void* fn = dtype == IDF_F16 ? (const void*)conv_in_kernel<IDF_F16> : (const void*)conv_in_kernel<IDF_BF16>;
-      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set[v] = true;
-    }
+    static std::atomic<unsigned long long> attr_set[2];
+    const void* fn = dtype == IDF_F16 ? (const void*)conv_in_kernel<IDF_F16> : (const void*)conv_in_kernel<IDF_BF16>;
+    if (const int e = idf_lds_optin(fn, 144 * 1024, attr_set[dtype == IDF_F16 ? 1 : 0])) return e;
   }
   static int n_cu = 0;
   if (n_cu == 0) {

@@ -331,12 +331,8 @@ __global__ __launch_bounds__(512, 2) void mlp320_kernel(const MlpParams p, const
 template <int DT>
 int launch_mlp320(const MlpParams& p, hipStream_t s) {
   void (*kern)(const MlpParams, const int) = mlp320_kernel<DT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (const int e = idf_lds_optin(reinterpret_cast<const void*>(kern), MLP_SMEM, attr_done)) return e;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   const int tiles = p.M / MLP_BM;

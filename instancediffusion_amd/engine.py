@@ -62,6 +62,7 @@ PAIR_HOIST = os.environ.get("IDF_PAIR_HOIST", "1")
 if PAIR_HOIST not in ("0", "1"):
     raise ValueError(f"IDF_PAIR_HOIST={PAIR_HOIST}: must be 0 or 1")
 PAIR_HOIST = PAIR_HOIST == "1"
+DEBUG_PAIRED = os.environ.get("IDF_DEBUG_PAIRED", "0") == "1"     # verify the paired=True guarantee on EVERY forward_cond call
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, period: int = 64) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -161,6 +162,7 @@ class UNetEngine:
         self.use_graphs = use_graphs and self.device.type == "cuda"
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
+        self._paired_checked: set = set()
         self._cond_cache: Dict[tuple, Cond] = {}
         self._slots: Dict[int, Cond] = {}                      # batch size -> static Cond the hipGraphs read from
         self._slot_bound: Dict[int, int] = {}
@@ -768,6 +770,14 @@ class UNetEngine:
         assert cond.B == B
         fuser_on = self.fuser_scale != 0.0
         key = (B, H, W, fuser_on, bool(paired))
+        if paired and (DEBUG_PAIRED or key not in self._paired_checked):
+            # the hoist computes the conditioning-free prefix for rows [0, B/2) only: a batch that is not a guidance pair would
+            # get silently wrong eps (and a captured graph would keep replaying the hoisted sequence).  Checked when a launch
+            # configuration is first used (one compare + host sync per key), on every call with IDF_DEBUG_PAIRED=1.
+            n = B // 2
+            if B % 2 or not (torch.equal(x[:n], x[n:]) and torch.equal(t[:n], t[n:])):
+                raise ValueError("forward_cond(paired=True): rows [B/2, B) must repeat the latent and timestep of rows [0, B/2)")
+            self._paired_checked.add(key)
         x_s = self.buf("io.x", x.shape, torch.float32)
         t_s = self.buf("io.t", (B,), torch.float32)
         eps_s = self.buf("io.eps", (B, self.n_out, H, W), torch.float32)

@@ -24,24 +24,17 @@ import torch
 from .diffusion import make_ddim_timesteps
 
 
-_UC_SHARED_SEEN: dict = {}
-
-
 def guided_uc_shared(uc: torch.Tensor) -> bool:
-    """Are all rows of the unconditional context the same tensor (stride-0 broadcast, or equal values)?  The stride test
-    costs nothing; the value test (a full-tensor compare and a host sync) runs once per distinct tensor state and is then
-    remembered under (storage address, shape, strides, in-place version)."""
+    """Are all rows of the unconditional context the same (stride-0 broadcast, or equal values)?  The stride test costs
+    nothing; the value test is one full-tensor compare and a host sync, run ONCE per ``sample()`` call on the live tensor.
+    (Round 4 memoised it under (address, shape, strides, version) -- a key that does not identify the tensor's CONTENT: a fresh
+    ``uc`` of another call can reuse the address at version 0 and hit a stale True, which silently broadcast row 0's negative
+    prompt to every image; ``_version`` also raises under inference_mode.  ADVICE r4.)"""
     if uc.shape[0] <= 1:
         return False
     if uc.stride(0) == 0:
         return True
-    key = (uc.device, uc.data_ptr(), tuple(uc.shape), tuple(uc.stride()), uc._version)
-    hit = _UC_SHARED_SEEN.get(key)
-    if hit is None:
-        if len(_UC_SHARED_SEEN) > 64:
-            _UC_SHARED_SEEN.clear()
-        hit = _UC_SHARED_SEEN[key] = bool((uc[1:] == uc[:1]).all())
-    return hit
+    return bool((uc[1:] == uc[:1]).all())
 
 
 class _PLMSBase(object):

@@ -183,8 +183,10 @@ def test_conv3x3_out_nchw(ops, ref):
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 4, 16, 16, 64), (3, 4, 10, 13, 320), (64, 4, 64, 64, 320), (1, 4, 96, 96, 320),
                                             (2, 4, 8, 6, 512)])
 def test_conv_in(ops, ref, B, Cin, H, W, Cout):
-    """First conv from the fp32 NCHW latent: persistent quad kernel (weights staged once per workgroup; 4 horizontally
-    adjacent pixels per thread), incl. widths that are not a multiple of 4, the bench shape and the VAE's 4 -> 512."""
+    """First conv from the fp32 NCHW latent.  The UNet's 4 -> 320 case runs on the matrix cores (round 4, conv_in_mfma_kernel:
+    both operands split into bf16 head + tail, K = 108, fp32-class accuracy); every other channel count -- incl. the VAE's
+    4 -> 512 -- on the persistent quad kernel (weights staged once per workgroup; 4 horizontally adjacent pixels per thread).
+    Widths that are not a multiple of 4 and the bench shape included."""
     x, w, b = gen((B, Cin, H, W), 28), gen((Cout, Cin, 3, 3), 29, 1 / 6), gen((Cout,), 30)
     want = ref.conv_in(x, w, b, torch.empty(B, H, W, Cout))
     out = ops.conv_in(dev(x), dev(w), dev(b), ops.empty((B, H, W, Cout)))

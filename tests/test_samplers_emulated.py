@@ -131,11 +131,25 @@ def _tile_batch(inp, rep):
                 gb={k: t(v) for k, v in inp["gb"].items()}, inst_ctx=[t(c) for c in inp["inst_ctx"]])
 
 
-def _dist_worker(rank, world, port, q, sharding="auto", rep=1):
+def _dist_worker(rank, world, port, q, sharding="auto", rep=1, count_collectives=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     torch.set_num_threads(WORKER_THREADS if rep == 1 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {}
+    if count_collectives:
+        # every communication entry point of torch.distributed the sampler could reach: a regression to per-step (or per-unit)
+        # communication shows up as a count that grows with S or N
+        for name in ("broadcast", "all_gather", "all_reduce", "reduce", "gather", "scatter", "all_to_all", "all_to_all_single",
+                     "all_gather_into_tensor", "reduce_scatter", "reduce_scatter_tensor", "send", "recv", "isend", "irecv",
+                     "barrier", "all_gather_object", "broadcast_object_list"):
+            if hasattr(dist, name):
+                def wrap(fn, name=name):
+                    def counted(*a, **k):
+                        calls[name] = calls.get(name, 0) + 1
+                        return fn(*a, **k)
+                    return counted
+                setattr(dist, name, wrap(getattr(dist, name)))
     gold, meta, inp, model, gi, diffusion = setup("tiny_box", batch_invariant=True)
     inp = _tile_batch(inp, rep)
     sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
@@ -143,15 +157,25 @@ def _dist_worker(rank, world, port, q, sharding="auto", rep=1):
     out = sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=mis_inputs(meta, inp, gi), uc=inp["uc"],
                          guidance_scale=7.5)
     # by value (numpy): a torch tensor would travel as a shared-memory handle that dies with this process
-    q.put((rank, out.numpy().copy(), sampler.engine.ops.rows.get("attention", 0)))
+    if count_collectives:
+        first = dict(calls)
+        calls.clear()
+        inputs = mis_inputs(meta, inp, gi)
+        for i in inputs:
+            i["x"] = None                                  # the sampler draws the start latent itself: rank 0's is broadcast
+        sampler.sample(S=meta["S"], shape=tuple(inp["x"].shape), input=inputs, uc=inp["uc"], guidance_scale=7.5)
+        q.put((rank, out.numpy().copy(), (first, dict(calls))))
+    else:
+        q.put((rank, out.numpy().copy(), sampler.engine.ops.rows.get("attention", 0)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("sharding", ["image", "instance"])
 def test_mis_sharded_world2_gloo(sharding):
-    """N>1 path: (instance, image) units sharded over 2 ranks (both ownership rules) + all-reduce merge + image-sharded
-    phase 2."""
+    """N>1 path: (instance, image) units sharded over 2 ranks (both ownership rules), ONE all-gather of the unit latents each
+    rank owns (scattered by index into the fixed [instance][image] stack) + the same idf_mis_merge as on one rank, image-sharded
+    phase 2 with a second all-gather of the finished images."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -283,3 +307,49 @@ def test_shared_unconditional_row_is_built_once_and_changes_nothing(monkeypatch)
         prepared.append(rows[0])
     assert torch.equal(outs[0], outs[1])
     assert prepared[0] == prepared[1] - (inp["uc"].shape[0] - 1), prepared
+
+
+def test_guided_uc_shared_looks_at_the_content_of_the_live_tensor():
+    """the test was memoised under (address, shape, strides, version), which a fresh tensor of a later sample() call
+    can reproduce with different content.  Now: a stride-0 broadcast is shared by construction, anything else is compared --
+    same storage rewritten in place (version bumped or not), tensors created under inference_mode (whose ``_version`` raises)."""
+    from instancediffusion_amd.host.samplers import guided_uc_shared
+    a = torch.randn(1, 77, 8)
+    assert guided_uc_shared(a.expand(4, 77, 8))
+    same = a.repeat(4, 1, 1)
+    assert guided_uc_shared(same)
+    same[2, 5, 3] += 1.0                                  # in place: same address, shape, strides
+    assert not guided_uc_shared(same)
+    same.data[2, 5, 3] -= 1.0                             # .data does not bump the version counter
+    same.data[2] = same.data[0]
+    assert guided_uc_shared(same)
+    same.data[3, 0, 0] = 7.0
+    assert not guided_uc_shared(same)
+    with torch.inference_mode():
+        inf = a.repeat(3, 1, 1)
+        assert guided_uc_shared(inf)
+        inf2 = torch.randn(3, 77, 8)
+        assert not guided_uc_shared(inf2)
+    assert not guided_uc_shared(a)                        # a single row: nothing to share
+
+
+def test_mis_sampler_issues_two_collectives_and_one_broadcast_per_sample_gloo():
+    """at W > 1 a whole ``PLMSSamplerInst.sample()`` -- S = 5 steps, N + 1 = 4 trajectories per image -- talks to
+    the other ranks exactly three times: ONE broadcast of the start latent (only when the sampler draws it itself), ONE all_gather of the owned unit latents at the merge
+    (north_star's "RCCL gather to recombine instance latents") and ONE all_gather of the finished images.  Every other
+    torch.distributed entry point stays untouched; a regression to per-step or per-unit communication fails here on CPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 23
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q, "instance", 1, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, _, (given, drawn) in res:
+        print(f"[rank {rank}] torch.distributed calls during sample(): start latent given {given}, drawn by the sampler {drawn}")
+        assert given == {"all_gather": 2}, (rank, given)
+        assert drawn == {"broadcast": 1, "all_gather": 2}, (rank, drawn)
+    assert (res[0][1] == res[1][1]).all()

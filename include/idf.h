@@ -87,7 +87,8 @@ const char* idf_build_info(void);
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
-enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2, IDF_STAT_ATTN8_LAUNCHES = 3 };
+enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2, IDF_STAT_ATTN8_LAUNCHES = 3,
+       IDF_STAT_GN_EPI_LAUNCHES = 4 /* idf_conv3x3 calls whose gn_partial came out of the conv epilogue, not the statistics pass */ };
 long long idf_get_stat(int stat);
 
 /* ---- GEMM: out[M,N] = epi( A[M,K] . W[N,K]^T ) ----------------------------------------------------------
@@ -173,6 +174,12 @@ typedef struct {
   int n_valid;      /* OUT_NCHW: number of real output channels (<= Cout) */
   int epi; int dtype;
   void* ws; long long ws_bytes;       /* optional fp32 split-K workspace, as in idf_gemm_args */
+  /* optional (ABI 5): GroupNorm(32) partial statistics of the OUTPUT as a by-product -- on return gn_partial holds, for every
+   * sample b and 64-row chunk k of its Ho*Wo output rows, (mean, M2) per group: gn_partial[((b * (Ho*Wo/64) + k) * 32 + g) * 2],
+   * i.e. exactly what idf_groupnorm_apply(.., nchunks = Ho*Wo/64) merges; the conv kernel leaves them from its epilogue
+   * registers (no pass over the output) where it can, else the call runs the statistics pass itself.  Needs Ho*Wo % 64 == 0,
+   * Cout % 32 == 0, ldo == Cout, a 16-bit NHWC output.  NULL = none.  (openaimodel.py:237-257: every ResBlock conv feeds a GroupNorm) */
+  float* gn_partial;
 } idf_conv3x3_args;
 int idf_conv3x3(const idf_conv3x3_args* a, void* stream);
 
@@ -210,6 +217,12 @@ int idf_attention(const idf_attn_args* a, void* stream);
 long long idf_groupnorm_ws_floats(int B, int HW);
 int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
                   int B, int HW, int C, float eps, int silu, int dtype, void* stream);
+/* The two halves of idf_groupnorm as separate calls (ABI 5): `partial` = [B][nchunks][32][2] fp32 (mean, M2) per (sample, row
+ * chunk, group), chunk k = rows [k rpc, (k + 1) rpc), rpc = ceil(HW / nchunks).  idf_groupnorm_apply accepts the partials of
+ * idf_groupnorm_stats or of a producer (idf_conv3x3's gn_partial, nchunks = HW / 64).  Bitwise run-to-run deterministic. */
+int idf_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int nchunks, int dtype, void* stream);
+int idf_groupnorm_apply(const void* x, void* out, const float* gamma, const float* beta, const float* partial,
+                        int B, int HW, int C, int nchunks, float eps, int silu, int dtype, void* stream);
 
 /* ---- LayerNorm over the last dim (attention.py:294-295,320-322), eps 1e-5 -------------------------------- */
 int idf_layernorm(const void* x, int ldx, void* out, int ldo, const float* gamma, const float* beta,

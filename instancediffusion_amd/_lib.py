@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDF_LIB_PATH", os.path.join(_HERE, "libidf_gfx950.so"))   # override: A/B builds only
 
 IDF_BF16, IDF_F16 = 0, 1
-IDF_STAT_GEMM_BIG_LAUNCHES, IDF_STAT_ATTN2_LAUNCHES, IDF_STAT_GEMM_RING_LAUNCHES, IDF_STAT_ATTN8_LAUNCHES = 0, 1, 2, 3   # idf_get_stat
+IDF_STAT_GEMM_BIG_LAUNCHES, IDF_STAT_ATTN2_LAUNCHES, IDF_STAT_GEMM_RING_LAUNCHES, IDF_STAT_ATTN8_LAUNCHES, IDF_STAT_GN_EPI_LAUNCHES = 0, 1, 2, 3, 4   # idf_get_stat
 IDF_TUNE_GEMM_BIG, IDF_TUNE_ATTN2, IDF_TUNE_GEMM_RING, IDF_TUNE_BIG_MIN_EFF, IDF_TUNE_ATTN8 = 0, 1, 2, 3, 4      # idf_set_tuning
 EPI_LN_ROW, EPI_LN_COL, EPI_GEGLU_P32 = 512, 1024, 2048
 EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \
@@ -39,7 +39,7 @@ class ConvArgs(C.Structure):
                 ("B", ci), ("Hin", ci), ("Win", ci), ("Cin", ci), ("Cout", ci),
                 ("stride", ci), ("upsample", ci),
                 ("ldx", ci), ("ldo", ci), ("ldr", ci), ("ld_rowbias", ci),
-                ("n_valid", ci), ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll)]
+                ("n_valid", ci), ("epi", ci), ("dtype", ci), ("ws", vp), ("ws_bytes", ll), ("gn_partial", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -69,6 +69,8 @@ SYMBOLS = {
     "idf_attention": (ci, [C.POINTER(AttnArgs), vp]),
     "idf_groupnorm_ws_floats": (ll, [ci, ci]),
     "idf_groupnorm": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]),
+    "idf_groupnorm_stats": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "idf_groupnorm_apply": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, ci, vp]),
     "idf_layernorm": (ci, [vp, ci, vp, ci, vp, vp, ci, ci, cf, ci, vp]),
     "idf_row_stats": (ci, [vp, ci, vp, ci, ci, cf, ci, vp]),
     "idf_layernorm_patch2": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, cf, ci, vp]),

@@ -107,7 +107,29 @@ __device__ __forceinline__ u32x4* stg_at(char* stg, int row, int pc) {
   return reinterpret_cast<u32x4*>(stg + row * 64 + ((pc ^ stg_f(row)) << 4));
 }
 
-template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false, bool STATS = false, bool GLU = false>
+// GST (round 5): GroupNorm statistics of the tile's OUTPUT as a by-product ("statistics out of the producer's
+// epilogue") -- per wave, for its 64 rows x BN/2 columns, one (mean, M2) pair per 32-group GroupNorm group into
+// p.gn_partial[sample][64-row chunk][group][2]: exactly the partial-summary layout gn_apply merges (norms.hip), so the
+// gn_stats pass over the tensor -- one full read of every conv output -- does not run.  From the 16-bit-ROUNDED values the
+// wave stores.  The accumulator layout is lane <-> row, register <-> column, so a group sum is a cross-LANE sum: per 32-column
+// fragment pair (b = 0, 1 combined in-lane) the lane's 16 shifted values d = y - bias[col] and their squares go through a
+// 5-step reduce-scatter over the 32 lanes of a half (31 ds_bpermute + 93 VALU), after which lane l holds the 64-row total of
+// d (l < 16) or d^2 (l >= 16) of column 16 hi + (l & 15); the 2 x 160 column totals pass through the wave's private 2-KB LDS
+// slot and 160 / cpg lanes merge their group's columns (equal counts: mean of means, M2 = sum M2_c + 64 sum (mean_c - mean)^2).
+// ~1100 VALU / LDS operations per wave and tile: 0.5-2 % of a 3x3 conv tile (90-180 K-tiles).
+template <int N, int L>
+__device__ __forceinline__ void gst_scatter_step(float* t, int l31) {
+  // N values per lane -> N/2: the lane keeps the half its bit L/... selects and adds its partner's copy of that half
+  constexpr int H = N / 2;
+  const bool up = (l31 & H) != 0;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const float keep = up ? t[i + H] : t[i];
+    const float send = up ? t[i] : t[i + H];
+    t[i] = keep + __shfl_xor(send, H, 64);
+  }
+}
+template <int DT, int BM, int BN, int TN, bool SPLIT, bool LNS = false, bool STATS = false, bool GLU = false, bool GST = false>
 __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[TN][TM], int seq, int slice, int tiles_n, int wm,
                                              int wn, int l31_in, int hi_in, float gate, char* stg_in, const float* lnm = nullptr,
                                              const float* lnr = nullptr) {
@@ -296,10 +318,12 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
     float st_p[TM], st_s1[TM], st_s2[TM];                  // STATS: pivot, sum (x - p), sum (x - p)^2 per row fragment
 #pragma unroll
     for (int b = 0; b < TM; ++b) { st_p[b] = 0.0f; st_s1[b] = 0.0f; st_s2[b] = 0.0f; }
+    float gacc[GST ? TN : 1];                               // GST: per fragment column a, this lane's column total (see above)
     static_for<0, TN, 1>([&](auto AI) {
       constexpr int a = decltype(AI)::value;
       const int n = nw + a * 32 + 16 * hi;
       f32x4 bs[4], cs[4];
+      float gt[GST ? 32 : 1];                               // GST: d and d^2 of the lane's 16 columns, summed over b
       if (epi & IDF_EPI_BIAS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bs[j] = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * j);
@@ -392,6 +416,17 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
             *reinterpret_cast<u32x4*>(o) = q0;
             *reinterpret_cast<u32x4*>(o + 8) = q1;
           }
+          if constexpr (GST) {
+            float r[16];
+            unpack8<DT>(q0, r);
+            unpack8<DT>(q1, r + 8);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const float d = (epi & IDF_EPI_BIAS) ? r[j] - bs[j >> 2][j & 3] : r[j];
+              if (b == 0) { gt[j] = d; gt[16 + j] = d * d; }
+              else { gt[j] += d; gt[16 + j] = fmaf(d, d, gt[16 + j]); }
+            }
+          }
           if constexpr (STATS) {
             float r[16];
             unpack8<DT>(q0, r);
@@ -402,7 +437,51 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           }
         }
       }
+      if constexpr (GST) {
+        gst_scatter_step<32, 0>(gt, l31);
+        gst_scatter_step<16, 0>(gt, l31);
+        gst_scatter_step<8, 0>(gt, l31);
+        gst_scatter_step<4, 0>(gt, l31);
+        gst_scatter_step<2, 0>(gt, l31);
+        gacc[a] = gt[0];
+      }
     });
+    if constexpr (GST) {
+      // column totals -> the wave's LDS slot: cs[kind][column of the wave's BN/2], kind 0 = sum d, 1 = sum d^2
+      float* const csl = reinterpret_cast<float*>(stg);
+      constexpr int WNC = BN / 2;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) csl[(l31 >> 4) * WNC + a * 32 + 16 * hi + (l31 & 15)] = gacc[a];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int cpg = p.N >> 5;                             // channels per group (32 groups); WNC % cpg == 0 (dispatcher)
+      const int g = l31 + 32 * hi;
+      if (g * cpg < WNC && mw < p.M) {
+        constexpr float rows = (float)WM, inv_rows = 1.0f / (float)WM;
+        const float inv_cpg = 1.0f / (float)cpg;
+        float ms = 0.f, q = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+          const int col = g * cpg + j;
+          const float s1 = csl[col], s2 = csl[WNC + col];
+          const float pc = (epi & IDF_EPI_BIAS) ? p.bias[nw + col] : 0.0f;
+          const float dm = s1 * inv_rows;
+          ms += pc + dm;
+          q += fmaxf(s2 - s1 * dm, 0.0f);
+        }
+        const float mean = ms * inv_cpg;
+        float dev = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+          const int col = g * cpg + j;
+          const float pc = (epi & IDF_EPI_BIAS) ? p.bias[nw + col] : 0.0f;
+          const float dd = pc + csl[col] * inv_rows - mean;
+          dev = fmaf(dd, dd, dev);
+        }
+        const int smp = mw / p.gn_hw, chunk = (mw - smp * p.gn_hw) / WM, nch = p.gn_hw / WM;
+        *reinterpret_cast<f32x2*>(p.gn_partial + (((size_t)smp * nch + chunk) * 32 + nw / cpg + g) * 2) =
+            f32x2{mean, fmaf(rows, dev, q)};
+      }
+      __builtin_amdgcn_wave_barrier();                      // the slot is reused by this wave's next tile
+    }
     if constexpr (STATS) {
       constexpr float cnt = 16.0f * TN;                      // values per lane and row: half of the wave's BN/2 columns
       const int n_tile = (seq - m_tile * tiles_n);
@@ -492,7 +571,7 @@ __device__ unsigned long long idf_big_trace_buf[4][8];
 // Geometry: BM x BN output tile, (BM/64) x 2 waves (wave tile 64 x BN/2), K-tile BKT, NSTG-stage LDS ring.
 //   <256, {320,256}, 64, 2>: ONE 8-wave workgroup per CU (2 x 72 KB stages); <256, 128, 64, 3>: 3 x 48 KB stages.
 template <int DT, int BM, int BN, int BKT, int NSTG, bool CONV, bool SPLIT, bool LNS = false, bool VT = false, bool STATS = false,
-          bool GLU = false>
+          bool GLU = false, bool GST = false>
 __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CoreParams p, const int tiles_total) {
   constexpr int WN = BN / 2, TN = WN / 32;
   constexpr int NW = NWAVES;                               // waves per workgroup: (BM / WM) x 2
@@ -853,7 +932,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void gemm_kernel_big(const CorePara
         big_epilogue_vt<DT, BM, BN, TN>(p, acc, seq, tiles_n, wm, wn, l31, hi, p.ln_stats, 0);
       }
     } else {
-      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, stg, lnm, lnr);
+      big_epilogue<DT, BM, BN, TN, SPL, LNS, STATS, GLU, GST>(p, acc, tile, slice, tiles_n, wm, wn, l31, hi, gate, stg, lnm, lnr);
     }
     TR(4)
     // store instructions this wave just issued, at least (see the first K-tile's wait above)
@@ -917,16 +996,17 @@ BigSched& big_sched() {
   return sc;
 }
 
-template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false, bool STATS = false, bool GLU = false>
+template <int DT, int BN, int NSTG, bool CONV, bool SPLIT = false, bool LNS = false, bool VT = false, bool STATS = false, bool GLU = false,
+          bool GST = false>
 int launch_big_cfg(const CoreParams& p, hipStream_t s, int splitk = 1) {
   constexpr int BM = 256, BKT = 64;
-  if constexpr (!SPLIT && !LNS && !VT && !STATS && !GLU && NSTG == 2) {
+  if constexpr (!SPLIT && !LNS && !VT && !STATS && !GLU && !GST && NSTG == 2) {
     if (splitk > 1) return launch_big_cfg<DT, BN, NSTG, CONV, true>(p, s, splitk);
   }
-  if constexpr (!SPLIT && !LNS && !CONV && !STATS && NSTG == 2) {
+  if constexpr (!SPLIT && !LNS && !CONV && !STATS && !GST && NSTG == 2) {
     if ((p.epi & IDF_EPI_LN_ROW) && !p.ln_stats) return launch_big_cfg<DT, BN, NSTG, CONV, false, true, VT, false, GLU>(p, s, 1);
   }
-  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS, GLU>;
+  void (*kern)(const CoreParams, const int) = gemm_kernel_big<DT, BM, BN, BKT, NSTG, CONV, SPLIT, LNS, VT, STATS, GLU, GST>;
   constexpr int smem = NSTG * (BM + BN) * BKT * 2 + NWAVES * 2048;      // ring + one 2-KB slot per wave (160 KB at BN = 320)
   static std::atomic<unsigned long long> attr_done{0};
   if (const int e = idf_lds_optin(reinterpret_cast<const void*>(kern), smem, attr_done)) return e;
@@ -977,7 +1057,8 @@ int idf_big_min_eff_pct(int set) {
 
 // Shape gate + tile-width choice.  `force` skips the occupancy heuristic, not the shape rules.
 int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out, int* parts_out,
-                   int* tail_m0_out) {
+                   int* tail_m0_out, int* gst_out) {
+  if (gst_out) *gst_out = 0;
   if (splitk_out) *splitk_out = 1;
   if (parts_out) *parts_out = 0;
   if (tail_m0_out) *tail_m0_out = 0;
@@ -1067,6 +1148,12 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
                      (size_t)p.M * (size_t)(2 * (p.N / bn)) * 2 * sizeof(float) <= p.ws_bytes;
   CoreParams ps = p;
   if (stats) { ps.parts = 2 * (p.N / bn); *parts_out = ps.parts; }
+  // GroupNorm partials of the output from the epilogue (GST): unsplit 3x3 convs on 320-wide tiles whose rows are whole 64-row
+  // chunks of one sample and whose wave column halves (160) hold whole groups
+  const bool gst = gst_out && p.gn_partial && conv && bn == 320 && splitk == 1 && full_items == 0 && !(p.epi & IDF_EPI_OUT_F32) &&
+                   p.gn_hw > 0 && (p.gn_hw % 64) == 0 && (p.M % p.gn_hw) == 0 && (p.N % 32) == 0 && (160 % (p.N / 32)) == 0 &&
+                   (((uintptr_t)p.gn_partial) & 7u) == 0;
+  if (gst) *gst_out = 1;
   CoreParams pq = p;                                      // split launches: uniform split-K (full 0) or hybrid
   pq.full_items = (int)full_items; pq.tail_m0 = tail_m0; pq.tail_rows = p.M - tail_m0;
   const bool glu320 = geglu && (p.epi & IDF_EPI_GEGLU_P32) && bn == 320;
@@ -1079,6 +1166,7 @@ int idf_launch_big(const CoreParams& p, int dtype, bool conv, bool force, hipStr
     if (conv) return launch_big_cfg<DT, 128, 3, true>(p, s);                                                              \
     return launch_big_cfg<DT, 128, 3, false>(p, s);                                                                       \
   }                                                                                                                       \
+  if (gst) return launch_big_cfg<DT, 320, 2, true, false, false, false, false, false, true>(p, s);                         \
   if (conv) return bn == 320 ? launch_big_cfg<DT, 320, 2, true>(pq, s, splitk) : launch_big_cfg<DT, 256, 2, true>(pq, s, splitk);   \
   return bn == 320 ? launch_big_cfg<DT, 320, 2, false>(pq, s, splitk) : launch_big_cfg<DT, 256, 2, false>(pq, s, splitk);
   if (dtype == IDF_BF16) { IDF_BIG_DISPATCH(IDF_BF16) }

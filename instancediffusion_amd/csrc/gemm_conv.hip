@@ -722,6 +722,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // profiles/r01_diag_B18_gemm_ring_vs_dma.log.  That was THROUGHPUT on grids of thousands of tiles, two workgroups per CU; the
 // latency kernel above (round 4: 64-deep K-steps, one barrier per 16 MFMAs, one workgroup per CU) serves the opposite regime --
 // grids of <= 256 tiles, where a launch is a chain of dependent trips to memory -- and is chosen by tile count in launch().
+std::atomic<long long> idf_stat_gn_epi_launches{0};   // idf_conv3x3 calls whose GroupNorm partials came out of the epilogue (idf_get_stat)
 std::atomic<long long> idf_stat_ring_launches{0};     // launches of the latency kernel (idf_get_stat)
 int g_big_mode = -2;
 inline int gemm_big_mode() {
@@ -841,7 +842,7 @@ int launch_ring_cfg(const CoreParams& p, int batch, hipStream_t s) {
 }
 
 template <int DT, bool CONV>
-int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullptr) {
+int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullptr, int* gst_out = nullptr) {
   const bool geglu = (p.epi & IDF_EPI_GEGLU) != 0;
   // tile choice: 128x128 when N fills it; 128(M) x 64(N) for N = 64 mod 128 (e.g. 320) or small N.  For the conv
   // (long K = 9*Cin) the denser 64x64 wave tile wins even with a half-empty last column tile at Cout = 320
@@ -863,7 +864,7 @@ int launch(const CoreParams& p, int batch, hipStream_t s, int* parts_out = nullp
   if (big > 0 && batch == 1 && !ring_first) {
     int splitk = 1, tail_m0 = 0;
     // mode 3 = automatic + hybrid tail split (the dispatcher only cuts a tail when it is given somewhere to report it)
-    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out, big == 3 ? &tail_m0 : nullptr);
+    const int rc = idf_launch_big(p, DT, CONV, big == 2, s, &splitk, parts_out, big == 3 ? &tail_m0 : nullptr, gst_out);
     if (rc != IDF_BIG_UNSUPPORTED) {
       if (rc == 0 && splitk > 1) {
         CoreParams q = p;
@@ -956,6 +957,7 @@ extern "C" long long idf_get_stat(int stat) {
   if (stat == IDF_STAT_ATTN2_LAUNCHES) return idf_stat_attn2_launches.load();
   if (stat == IDF_STAT_GEMM_RING_LAUNCHES) return idf_stat_ring_launches.load();
   if (stat == IDF_STAT_ATTN8_LAUNCHES) return idf_stat_attn8_launches.load();
+  if (stat == IDF_STAT_GN_EPI_LAUNCHES) return idf_stat_gn_epi_launches.load();
   return -1;
 }
 
@@ -1079,7 +1081,19 @@ extern "C" int idf_conv3x3(const idf_conv3x3_args* a, void* stream) {
   p.ws = (float*)a->ws; p.ws_bytes = a->ws ? (size_t)a->ws_bytes : 0;
   if ((a->epi & IDF_EPI_ROWBIAS) && !a->rowbias) return IDF_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == IDF_BF16) return launch<IDF_BF16, true>(p, 1, s);
-  if (a->dtype == IDF_F16) return launch<IDF_F16, true>(p, 1, s);
-  return IDF_E_UNSUPPORTED;
+  if (a->gn_partial) {
+    // GroupNorm partials of the output (see idf.h): whole 64-row chunks per sample, 32 groups, a 16-bit NHWC output matrix
+    const int hw = p.Ho * p.Wo;
+    if ((hw % 64) || (a->Cout % 32) || a->ldo != a->Cout || (a->epi & (IDF_EPI_OUT_F32 | IDF_EPI_OUT_NCHW))) return IDF_E_ARG;
+    if (((uintptr_t)a->gn_partial) & 7u) return IDF_E_ALIGN;
+    p.gn_partial = a->gn_partial; p.gn_hw = hw;
+  }
+  int gst = 0, rc = IDF_E_UNSUPPORTED;
+  if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, true>(p, 1, s, nullptr, &gst);
+  else if (a->dtype == IDF_F16) rc = launch<IDF_F16, true>(p, 1, s, nullptr, &gst);
+  // the contract holds whichever kernel took the launch: where the epilogue did not leave the partials, the statistics pass does
+  if (rc == 0 && gst) ++idf_stat_gn_epi_launches;
+  if (rc == 0 && a->gn_partial && !gst)
+    rc = idf_groupnorm_stats(a->out, a->gn_partial, a->B, p.Ho * p.Wo, a->Cout, p.Ho * p.Wo / 64, a->dtype, stream);
+  return rc;
 }

@@ -30,6 +30,9 @@ struct CoreParams {
   // out_stats by-product of the persistent kernel: every wave leaves (mean, M2) of the BN/2 output columns it owns of a row
   // in stat_parts[(m * parts + tile_n * 2 + wn) * 2 ..] (fp32, workspace); stats_finalize merges the `parts` slots of a row
   float* stat_parts; int parts;
+  // GroupNorm partials of the output as a by-product of the persistent kernel's conv epilogue (round 5): (mean, M2) per
+  // (sample, 64-row chunk, group) in gn_partial[sample][gn_hw / 64][32][2]; gn_hw = rows per sample
+  float* gn_partial; int gn_hw;
   // persistent-kernel schedule (round 4; every setting computes the same bits): tile_walk 0 = strided, 1 = chunked;
   // dephase = P start groups per XCD (0 / 1: off), dephase_units = one tile's estimated duration in units of 1024 cycles;
   // epi_vmcnt = 1: the first K-tile behind an epilogue waits with a counted vmcnt (the epilogue's stores drain under it)
@@ -135,8 +138,9 @@ extern std::atomic<long long> idf_stat_big_launches;     // process-global launc
 // *splitk_out > 1 on return: the kernel left fp32 partials of that many K-slices in p.ws; the caller runs the reducer
 // *parts_out (optional): > 0 when the kernel left per-wave partial output-row statistics in p.stat_parts (p.stat_parts
 // offered and the launch was an unsplit dense GEMM), the number of slots per row.
+// *gst_out (optional): 1 when the kernel left the GroupNorm partials of its output in p.gn_partial (see CoreParams).
 int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out,
-                   int* parts_out = nullptr, int* tail_m0_out = nullptr);
+                   int* parts_out = nullptr, int* tail_m0_out = nullptr, int* gst_out = nullptr);
 int idf_big_min_eff_pct(int set);                        // automatic rule's occupancy bar in per cent (set < 0: query)
 int idf_num_cu();                                        // CUs of the current device (cached)
 // (mu, rstd) per row from `parts` equal-count (mean, M2) slots per row (fixed merge order): out_stats[m] = f32x2

@@ -282,36 +282,66 @@ extern "C" long long idf_groupnorm_ws_floats(int B, int HW) {
   return (long long)B * gn_nchunks(HW) * GN_GROUPS * 2;
 }
 
-extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
-                             int B, int HW, int C, float eps, int silu, int dtype, void* stream) {
-  if (!x || !out || !gamma || !beta || !ws) return IDF_E_ARG;
-  if (B <= 0 || HW <= 0 || C <= 0 || (C % 32) || (C % 8)) return IDF_E_ARG;
-  if (!aligned16(x) || !aligned16(out)) return IDF_E_ALIGN;
+namespace {
+int gn_unroll() {
+  static int unr = -1;                                          // rows in flight per thread (IDF_GN_UNROLL=1|4 for A/B runs)
+  if (unr < 0) { const char* e = getenv("IDF_GN_UNROLL"); unr = (e && atoi(e) == 1) ? 1 : 4; }
+  return unr;
+}
+}  // namespace
+
+// The two halves of GroupNorm as separate entry points (round 5): the statistics pass can be replaced by a producer's
+// by-product (idf_conv3x3's gn_partial).  partial = [B][nchunks][32][2] fp32 (mean, M2); chunk k = rows [k rpc, (k + 1) rpc) of a
+// sample, rpc = ceil(HW / nchunks).
+extern "C" int idf_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int nchunks, int dtype, void* stream) {
+  if (!x || !partial) return IDF_E_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || (C % 32) || (C % 8) || nchunks <= 0 || nchunks > HW) return IDF_E_ARG;
+  if (!aligned16(x)) return IDF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  const int nchunks = gn_nchunks(HW);
   const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
   const size_t sm1 = (size_t)2 * TY * C * sizeof(float);
+  if (sm1 > 64 * 1024) return IDF_E_UNSUPPORTED;
+  dim3 g1(nchunks, B);
+  const int unr = gn_unroll();
+#define IDF_GN_STATS(DT, U) hipLaunchKernelGGL((gn_stats_kernel<DT, U>), g1, dim3(256), sm1, s, (const unsigned short*)x, partial, HW, C, nchunks);
+  if (dtype == IDF_BF16) { if (unr == 1) { IDF_GN_STATS(IDF_BF16, 1) } else { IDF_GN_STATS(IDF_BF16, 4) } }
+  else if (dtype == IDF_F16) { if (unr == 1) { IDF_GN_STATS(IDF_F16, 1) } else { IDF_GN_STATS(IDF_F16, 4) } }
+  else return IDF_E_UNSUPPORTED;
+#undef IDF_GN_STATS
+  return idf_launch_status();
+}
+
+extern "C" int idf_groupnorm_apply(const void* x, void* out, const float* gamma, const float* beta, const float* partial,
+                                   int B, int HW, int C, int nchunks, float eps, int silu, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta || !partial) return IDF_E_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || (C % 32) || (C % 8) || nchunks <= 0 || nchunks > HW) return IDF_E_ARG;
+  if (!aligned16(x) || !aligned16(out)) return IDF_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int cpr = C / 8, TX = cpr < 256 ? cpr : 256, TY = 256 / TX;
   const size_t sm2 = (size_t)((2 * C > 512 ? 2 * C : 512) + 2 * GN_GROUPS) * sizeof(float);
-  if (sm1 > 64 * 1024 || sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
+  if (sm2 > 64 * 1024) return IDF_E_UNSUPPORTED;
   int nblk = (HW + TY * 8 - 1) / (TY * 8);                       // >= 8 rows per thread-row, <= 256 blocks per batch
   if (nblk < 1) nblk = 1;
   if (nblk > 256) nblk = 256;
-  dim3 g1(nchunks, B), g2(nblk, B);
-  static int unr = -1;                                          // rows in flight per thread (IDF_GN_UNROLL=1|4 for A/B runs)
-  if (unr < 0) { const char* e = getenv("IDF_GN_UNROLL"); unr = (e && atoi(e) == 1) ? 1 : 4; }
-#define IDF_GN_LAUNCH(DT, U)                                                                                              \
-  hipLaunchKernelGGL((gn_stats_kernel<DT, U>), g1, dim3(256), sm1, s, (const unsigned short*)x, ws, HW, C, nchunks);      \
+  dim3 g2(nblk, B);
+  const int unr = gn_unroll();
+#define IDF_GN_APPLY(DT, U)                                                                                               \
   hipLaunchKernelGGL((gn_apply_kernel<DT, U>), g2, dim3(256), sm2, s, (const unsigned short*)x, (unsigned short*)out,     \
-                     gamma, beta, ws, HW, C, nchunks, eps, silu, nblk);
-  if (dtype == IDF_BF16) {
-    if (unr == 1) { IDF_GN_LAUNCH(IDF_BF16, 1) } else { IDF_GN_LAUNCH(IDF_BF16, 4) }
-  } else if (dtype == IDF_F16) {
-    if (unr == 1) { IDF_GN_LAUNCH(IDF_F16, 1) } else { IDF_GN_LAUNCH(IDF_F16, 4) }
-  } else {
-    return IDF_E_UNSUPPORTED;
-  }
-#undef IDF_GN_LAUNCH
+                     gamma, beta, partial, HW, C, nchunks, eps, silu, nblk);
+  if (dtype == IDF_BF16) { if (unr == 1) { IDF_GN_APPLY(IDF_BF16, 1) } else { IDF_GN_APPLY(IDF_BF16, 4) } }
+  else if (dtype == IDF_F16) { if (unr == 1) { IDF_GN_APPLY(IDF_F16, 1) } else { IDF_GN_APPLY(IDF_F16, 4) } }
+  else return IDF_E_UNSUPPORTED;
+#undef IDF_GN_APPLY
   return idf_launch_status();
+}
+
+extern "C" int idf_groupnorm(const void* x, void* out, const float* gamma, const float* beta, float* ws,
+                             int B, int HW, int C, float eps, int silu, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta || !ws) return IDF_E_ARG;
+  const int nchunks = gn_nchunks(HW > 0 ? HW : 1);
+  const int rc = idf_groupnorm_stats(x, ws, B, HW, C, nchunks, dtype, stream);
+  if (rc) return rc;
+  return idf_groupnorm_apply(x, out, gamma, beta, ws, B, HW, C, nchunks, eps, silu, dtype, stream);
 }
 
 extern "C" int idf_layernorm(const void* x, int ldx, void* out, int ldo, const float* gamma, const float* beta,

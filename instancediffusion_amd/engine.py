@@ -62,6 +62,12 @@ PAIR_HOIST = os.environ.get("IDF_PAIR_HOIST", "1")
 if PAIR_HOIST not in ("0", "1"):
     raise ValueError(f"IDF_PAIR_HOIST={PAIR_HOIST}: must be 0 or 1")
 PAIR_HOIST = PAIR_HOIST == "1"
+# Round 5: every 3x3 conv whose output feeds a GroupNorm leaves that GroupNorm's partial statistics from its epilogue registers
+# (idf_conv3x3 gn_partial), and the GroupNorm runs its normalise pass only.  IDF_GN_EPI=0: every GroupNorm runs both passes.
+GN_EPI = os.environ.get("IDF_GN_EPI", "1")
+if GN_EPI not in ("0", "1"):
+    raise ValueError(f"IDF_GN_EPI={GN_EPI}: must be 0 or 1")
+GN_EPI = GN_EPI == "1"
 DEBUG_PAIRED = os.environ.get("IDF_DEBUG_PAIRED", "0") == "1"     # verify the paired=True guarantee on EVERY forward_cond call
 
 
@@ -541,20 +547,29 @@ class UNetEngine:
     # =================================================================================================
     # forward
     # =================================================================================================
-    def _res(self, p, x, emb_all, out_role):
+    def _gnp(self, role, B, HW, C):
+        """Buffer for the GroupNorm partial statistics a conv3x3 leaves for the GroupNorm that reads its output, or None."""
+        shape = self.ops.gn_partial_shape(B, HW, C) if (GN_EPI and hasattr(self.ops, "gn_partial_shape")) else None
+        return None if shape is None else self.buf(role, shape, torch.float32)
+
+    def _res(self, p, x, emb_all, out_role, gnp=None):
+        """ResBlock (openaimodel.py:237-257).  ``gnp``: partial GroupNorm statistics of x left by its producer, or None.
+        Returns (h, partial statistics of h for the next layer's GroupNorm, or None)."""
         ops = self.ops
         B, H, W, Cin = x.shape
         Cout = p["cout"]
-        g = ops.groupnorm(x, self.buf("gn", x.shape), p["gn1"][0], p["gn1"][1], 1e-5, True)
+        g = ops.groupnorm(x, self.buf("gn", x.shape), p["gn1"][0], p["gn1"][1], 1e-5, True, partial=gnp)
         rb = emb_all[:, p["emb_off"]:p["emb_off"] + Cout]
-        h1 = ops.conv3x3(g, p["conv1"].w, self.buf("rb.h1", (B, H, W, Cout)), bias=p["conv1"].b, rowbias=rb)
-        g2 = ops.groupnorm(h1, self.buf("gn", h1.shape), p["gn2"][0], p["gn2"][1], 1e-5, True)
+        p1 = self._gnp("gnp.h1", B, H * W, Cout)
+        h1 = ops.conv3x3(g, p["conv1"].w, self.buf("rb.h1", (B, H, W, Cout)), bias=p["conv1"].b, rowbias=rb, gn_partial=p1)
+        g2 = ops.groupnorm(h1, self.buf("gn", h1.shape), p["gn2"][0], p["gn2"][1], 1e-5, True, partial=p1)
         if p["skip"] is not None:
             xs = ops.gemm(x.view(B * H * W, Cin), p["skip"].w, self.buf("rb.skip", (B * H * W, Cout)),
                           bias=p["skip"].b).view(B, H, W, Cout)
         else:
             xs = x
-        return ops.conv3x3(g2, p["conv2"].w, self.buf(out_role, (B, H, W, Cout)), bias=p["conv2"].b, res=xs)
+        p2 = self._gnp("gnp.out", B, H * W, Cout)
+        return ops.conv3x3(g2, p["conv2"].w, self.buf(out_role, (B, H, W, Cout)), bias=p["conv2"].b, res=xs, gn_partial=p2), p2
 
     def _self_attn(self, a, y, st, B, N, C, kv_extra=None, vis=None):
         """y [B*N, C] residual stream (raw), st [B*N, 2] its LayerNorm statistics (mu, rstd); the LayerNorm itself is folded
@@ -621,7 +636,7 @@ class UNetEngine:
         out[n:].copy_(t)
         return out
 
-    def _st(self, p, x, cond: Cond, fuser_on: bool, dup: bool = False):
+    def _st(self, p, x, cond: Cond, fuser_on: bool, dup: bool = False, gnp=None):
         """SpatialTransformer (attention.py:366-379).  No LayerNorm kernel runs: every GEMM that reads LN(y) reads y itself
         against gamma-folded weights and applies (mu, rstd) in its epilogue.  The q/k and cross-q projections sum their A
         rows in their own K loop (the q/k one hands the statistics to the transposed-V projection); the GEGLU GEMMs take
@@ -631,7 +646,7 @@ class UNetEngine:
         ops = self.ops
         B, H, W, C = x.shape
         N, M = H * W, B * H * W
-        g = ops.groupnorm(x, self.buf("gn", x.shape), p["norm"][0], p["norm"][1], 1e-6, False)
+        g = ops.groupnorm(x, self.buf("gn", x.shape), p["norm"][0], p["norm"][1], 1e-6, False, partial=gnp)
         st = self.buf("st.stats", (M, 2), torch.float32)
         own = self._ln_self(C)
         pre, ffs = (None if own else st), (st if LN_SELF_MODE <= 1 else None)   # which producers emit statistics
@@ -670,25 +685,32 @@ class UNetEngine:
         ops.gemm(y, p["proj_out"].w, x.view(M, C), bias=p["proj_out"].b, res=x.view(M, C))
         return x
 
-    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role, dup_st: bool = False):
+    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role, dup_st: bool = False, gnp=None):
+        """One TimestepEmbedSequential.  ``gnp``: partial GroupNorm statistics of h left by the conv that produced it (or None);
+        they are handed from a producing conv to the layer that follows IMMEDIATELY and dropped by anything else -- a
+        SpatialTransformer rewrites its input buffer in place.  Returns (h, partial statistics of h or None)."""
         for j, p in enumerate(layers):
             k = p["kind"]
             if k == "conv_in":
                 B, _, H, W = x_nchw.shape
                 h = self.ops.conv_in(x_nchw, p["w"], p["b"], self.buf(out_role, (B, H, W, p["w"].shape[0])))
+                gnp = None
             elif k == "res":
-                h = self._res(p, h, emb_all, out_role)
+                h, gnp = self._res(p, h, emb_all, out_role, gnp)
             elif k == "st":
-                h = self._st(p, h, cond, fuser_on, dup=dup_st)
+                h = self._st(p, h, cond, fuser_on, dup=dup_st, gnp=gnp)
+                gnp = None
             elif k == "down":
                 B, H, W, C = h.shape
-                h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role, (B, (H + 1) // 2, (W + 1) // 2, C)),
-                                     bias=p["conv"].b, stride=2)
+                Ho, Wo = (H + 1) // 2, (W + 1) // 2
+                gnp = self._gnp("gnp.out", B, Ho * Wo, C)
+                h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role, (B, Ho, Wo, C)), bias=p["conv"].b, stride=2, gn_partial=gnp)
             elif k == "up":
                 B, H, W, C = h.shape
                 h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role + ".up", (B, 2 * H, 2 * W, C)),
                                      bias=p["conv"].b, upsample=1)
-        return h
+                gnp = None                                      # feeds the ScaleU concat, not a GroupNorm
+        return h, gnp
 
     def _forward_ops(self, x: torch.Tensor, t_f32: torch.Tensor, cond: Cond, eps: torch.Tensor, fuser_on: bool,
                      paired: bool = False):
@@ -706,24 +728,24 @@ class UNetEngine:
         es = ops.gemm(e1, self.te2.w, self.buf("temb.2", (B, 4 * mc)), bias=self.te2.b, act="silu")   # silu(emb)
         emb_all = ops.gemm(es, self.emb_all.w, self.buf("temb.all", (B, self.emb_total)), bias=self.emb_all.b)
         hs = []
-        h = None
+        h, gnp = None, None
         for i, layers in enumerate(self.in_blocks):
             if hoist and i == 0:
-                h = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in0.half")
+                h, gnp = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in0.half")
                 hs.append(self._dup(h, "in0"))
                 continue
             if hoist and i == 1:
-                h = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in1.half", dup_st=True)
+                h, gnp = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in1.half", dup_st=True, gnp=gnp)
                 hs.append(h)
                 continue
-            h = self._run_block(layers, h, x, emb_all, cond, fuser_on, f"in{i}")
+            h, gnp = self._run_block(layers, h, x, emb_all, cond, fuser_on, f"in{i}", gnp=gnp)
             hs.append(h)
-        h = self._run_block(self.mid_block, h, x, emb_all, cond, fuser_on, "mid")
+        h, gnp = self._run_block(self.mid_block, h, x, emb_all, cond, fuser_on, "mid", gnp=gnp)
         for i, layers in enumerate(self.out_blocks):
             skip = hs.pop()
             Bq, H, W, Ch = h.shape
             cat = ops.scaleu_concat(h, skip, self.buf("cat", (Bq, H, W, Ch + skip.shape[-1])), *self.scaleu[i])
-            h = self._run_block(layers, cat, x, emb_all, cond, fuser_on, f"out{i}")
+            h, gnp = self._run_block(layers, cat, x, emb_all, cond, fuser_on, f"out{i}")
         g = ops.groupnorm(h, self.buf("gn", h.shape), self.out_gn[0], self.out_gn[1], 1e-5, True)
         ops.conv3x3(g, self.out_conv.w, eps, bias=self.out_conv.b, n_valid=self.n_out)
         return eps

@@ -187,9 +187,16 @@ class HipOps:
         _lib.check(self.lib.idf_mlp_geglu(C.byref(args), self._stream()), "idf_mlp_geglu")
         return out
 
-    def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
+    @staticmethod
+    def gn_partial_shape(B, HW, C):
+        """Shape of the GroupNorm partial-statistics buffer a conv3x3 can fill for its output ([B, HW/64, 32, 2] fp32), or
+        None when the output does not qualify (whole 64-row chunks per sample, 32 groups)."""
+        return (B, HW // 64, 32, 2) if (HW % 64 == 0 and C % 32 == 0) else None
+
+    def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0, gn_partial=None):
         """x [B,H,W,Cin] view (channel-contiguous), w [Cout, 9*Cin]; out [B,Ho,Wo,Cout] 16-bit, or fp32 NCHW
-        [B,n_valid,Ho,Wo] when ``n_valid`` > 0 (final conv)."""
+        [B,n_valid,Ho,Wo] when ``n_valid`` > 0 (final conv).  ``gn_partial`` (fp32 [B, Ho*Wo/64, 32, 2], see
+        ``gn_partial_shape``): filled with the GroupNorm partial statistics of the output, for ``groupnorm(.., partial=)``."""
         B, H, W_, Cin = x.shape
         assert x.stride(-1) == 1 and x.stride(1) == W_ * x.stride(2) and x.stride(0) == H * x.stride(1)
         Cout = w.shape[0]
@@ -214,7 +221,11 @@ class HipOps:
             B=B, Hin=H, Win=W_, Cin=Cin, Cout=Cout, stride=stride, upsample=upsample,
             ldx=x.stride(2), ldo=ldo, ldr=0 if res is None else res.stride(2),
             ld_rowbias=0 if rowbias is None else rowbias.stride(-2), n_valid=n_valid, epi=epi, dtype=self.dt,
-            ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES)
+            ws=self._splitk_ws().data_ptr(), ws_bytes=self.SPLITK_WS_BYTES,
+            gn_partial=None if gn_partial is None else gn_partial.data_ptr())
+        if gn_partial is not None:
+            assert gn_partial.dtype == torch.float32 and gn_partial.is_contiguous() and out.is_contiguous()
+            assert tuple(gn_partial.shape) == self.gn_partial_shape(out.shape[0], out.shape[1] * out.shape[2], Cout)
         _lib.check(self.lib.idf_conv3x3(C.byref(args), self._stream()), "idf_conv3x3")
         return out
 
@@ -250,11 +261,18 @@ class HipOps:
         _lib.check(self.lib.idf_attention(C.byref(a), self._stream()), "idf_attention")
         return out
 
-    def groupnorm(self, x, out, gamma, beta, eps, silu):
-        """x/out [B, HW, C] (or [B,H,W,C]) contiguous."""
+    def groupnorm(self, x, out, gamma, beta, eps, silu, partial=None):
+        """x/out [B, HW, C] (or [B,H,W,C]) contiguous.  ``partial``: the statistics of x are already there ([B, nchunks, 32, 2]
+        fp32 (mean, M2) per row chunk, as a conv3x3 leaves them): only the normalise pass runs."""
         assert x.is_contiguous() and out.is_contiguous()
         B, Cc = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * Cc)
+        if partial is not None:
+            assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.shape[0] == B and partial.shape[2:] == (32, 2)
+            _lib.check(self.lib.idf_groupnorm_apply(_p(x), _p(out), _p(gamma), _p(beta), _p(partial), B, HW, Cc,
+                                                    int(partial.shape[1]), float(eps), int(bool(silu)), self.dt,
+                                                    self._stream()), "idf_groupnorm_apply")
+            return out
         ws = self._workspace("gn", self.lib.idf_groupnorm_ws_floats(B, HW))
         _lib.check(self.lib.idf_groupnorm(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), B, HW, Cc, float(eps),
                                           int(bool(silu)), self.dt, self._stream()), "idf_groupnorm")

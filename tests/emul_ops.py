@@ -129,7 +129,11 @@ class EmulOps:
         mid = self.gemm(x, w1, torch.empty((M, 4 * C), dtype=self.dtype), bias=d1, geglu=True, geglu_period=32, ln_row=(stats, c1))
         return self.gemm(mid, w2, out, bias=b2, res=x, gate=gate)
 
-    def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0):
+    @staticmethod
+    def gn_partial_shape(B, HW, C):
+        return (B, HW // 64, 32, 2) if (HW % 64 == 0 and C % 32 == 0) else None
+
+    def conv3x3(self, x, w, out, *, bias=None, rowbias=None, res=None, stride=1, upsample=0, n_valid=0, gn_partial=None):
         self._count("conv3x3")
         B, H, W_, Cin = x.shape
         assert Cin % 64 == 0
@@ -152,6 +156,15 @@ class EmulOps:
             out.copy_(y[:, :n_valid])
         else:
             out.copy_(y.permute(0, 2, 3, 1))
+        if gn_partial is not None:
+            # (mean, M2) per (sample, 64-row chunk, group) of the STORED output, as the HIP conv epilogue leaves them
+            Bo, Cc = out.shape[0], out.shape[-1]
+            assert tuple(gn_partial.shape) == self.gn_partial_shape(Bo, out.shape[1] * out.shape[2], Cc)
+            v = out.float().reshape(Bo, -1, 64, 32, Cc // 32).permute(0, 1, 3, 2, 4).reshape(Bo, gn_partial.shape[1], 32, -1)
+            mean = v.mean(-1)
+            gn_partial[..., 0] = mean
+            gn_partial[..., 1] = ((v - mean[..., None]) ** 2).sum(-1)
+            self._count("conv3x3_gn_partial")
         return out
 
     def conv_in(self, x_nchw, w, bias, out):
@@ -199,11 +212,24 @@ class EmulOps:
         out.copy_(o.permute(0, 2, 1, 3).reshape(B, Nq, C))
         return out
 
-    def groupnorm(self, x, out, gamma, beta, eps, silu):
+    def groupnorm(self, x, out, gamma, beta, eps, silu, partial=None):
         self._count("groupnorm")
         B, C = x.shape[0], x.shape[-1]
         xi = x.float().reshape(B, -1, C).permute(0, 2, 1)
-        y = F.group_norm(xi, 32, gamma, beta, eps)
+        if partial is not None:
+            # merge the chunk partials (equal counts n = rows_per_chunk * C / 32) like gn_apply_kernel and normalise with them
+            self._count("groupnorm_from_partial")
+            HW = xi.shape[2]
+            nch = partial.shape[1]
+            n = (HW // nch) * (C // 32)
+            pm, pq = partial[..., 0].double(), partial[..., 1].double()            # [B, nch, 32]
+            mu = pm.mean(1)
+            var = (pq.sum(1) + n * ((pm - mu[:, None]) ** 2).sum(1)) / (n * nch)
+            mu_c = mu.float().repeat_interleave(C // 32, 1)[:, :, None]
+            rs_c = torch.rsqrt(var.float() + eps).repeat_interleave(C // 32, 1)[:, :, None]
+            y = (xi - mu_c) * rs_c * gamma.view(1, -1, 1) + beta.view(1, -1, 1)
+        else:
+            y = F.group_norm(xi, 32, gamma, beta, eps)
         if silu:
             y = F.silu(y)
         out.copy_(y.permute(0, 2, 1).reshape(x.shape))

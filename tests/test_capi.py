@@ -114,7 +114,7 @@ def test_argument_validation_without_gpu():
     assert lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 77)
     assert prev >= 0 and lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, prev) == 77
-    assert lib.idf_get_stat(_lib.IDF_STAT_GEMM_RING_LAUNCHES) == 0 and lib.idf_get_stat(4) == -1
+    assert lib.idf_get_stat(_lib.IDF_STAT_GEMM_RING_LAUNCHES) == 0 and lib.idf_get_stat(5) == -1 and lib.idf_get_stat(_lib.IDF_STAT_GN_EPI_LAUNCHES) == 0
     assert lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 0) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 101) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, 60)
     assert 1 <= prev <= 100 and lib.idf_set_tuning(_lib.IDF_TUNE_BIG_MIN_EFF, prev) == 60

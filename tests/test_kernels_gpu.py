@@ -1252,6 +1252,74 @@ def test_attention_v4_reference_value_paths(ref, attn4, case):
 
 
 # ---------------------------------------------------------------------------------------------------
+# GroupNorm partial statistics out of the conv epilogue (round 5: idf_conv3x3 gn_partial + idf_groupnorm_apply)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,extra,epi_path", [
+    (8, 64, 320, 320, 1, "rowbias", True),        # ResBlock conv1 at 64^2: 128 tiles, 16 groups per wave column half
+    (32, 32, 640, 640, 1, "res", True),           # conv2 + skip at 32^2: two n-tiles of 8 groups per wave column half
+    (64, 16, 1280, 1280, 1, "rowbias", True),     # 16^2: one 256-row tile per sample, four n-tiles of 8 groups
+    (64, 64, 320, 320, 2, None, True),            # Downsample (stride 2): 32^2 outputs
+    (16, 32, 640, 640, 1, "res", False),          # 128 tiles of a long K: split-K launch -> the statistics pass fills the buffer
+    (128, 8, 1280, 1280, 1, "res", False),        # 8^2: split-K launch -> the statistics pass fills the buffer
+    (2, 16, 320, 320, 1, "rowbias", False)])      # small grid (latency kernel) -> statistics pass
+def test_conv3x3_gn_partial(ref, dt, B, H, Cin, Cout, stride, extra, epi_path):
+    """The conv leaves (mean, M2) per (sample, 64-row chunk, group) of the 16-bit output it stores.  Checked (a) against fp64
+    statistics of that output, chunk by chunk, (b) GroupNorm from the partials == GroupNorm with its own statistics pass to
+    fp32 summation order, (c) which path filled the buffer (launch counter), (d) the conv output itself is bit-identical to the
+    call without gn_partial, (e) run-to-run bitwise determinism."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import pack_conv3x3
+    from instancediffusion_amd.ops import HipOps
+    ops = HipOps(dt)
+    lib = _lib.load()
+    x = (gen((B, H, H, Cin), 120) * 0.5).to(dt)
+    w = gen((Cout, Cin, 3, 3), 121, (9 * Cin) ** -0.5)
+    wp = pack_conv3x3(w).to(dt)
+    bias = gen((Cout,), 122) * 2.0 + 0.5                       # group means well away from 0
+    Ho = (H - 1) // stride + 1
+    kw = {}
+    if extra == "rowbias":
+        kw["rowbias"] = dev(gen((B, Cout), 123).to(dt))
+    if extra == "res":
+        kw["res"] = dev(gen((B, Ho, Ho, Cout), 124).to(dt))
+    shape = ops.gn_partial_shape(B, Ho * Ho, Cout)
+    assert shape == (B, Ho * Ho // 64, 32, 2)
+    part = ops.empty(shape, torch.float32)
+    part.fill_(float("nan"))
+    c0 = lib.idf_get_stat(_lib.IDF_STAT_GN_EPI_LAUNCHES)
+    out = ops.conv3x3(dev(x), dev(wp), ops.empty((B, Ho, Ho, Cout)), bias=dev(bias), stride=stride, gn_partial=part, **kw)
+    torch.cuda.synchronize()
+    assert (lib.idf_get_stat(_lib.IDF_STAT_GN_EPI_LAUNCHES) - c0 == 1) == epi_path
+    plain = ops.conv3x3(dev(x), dev(wp), ops.empty((B, Ho, Ho, Cout)), bias=dev(bias), stride=stride, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain), "asking for the statistics must not change the conv output"
+    assert torch.isfinite(part).all()
+    # (a) fp64 statistics of the stored output
+    cpg = Cout // 32
+    v = out.double().cpu().reshape(B, -1, 64, 32, cpg).permute(0, 1, 3, 2, 4).reshape(B, shape[1], 32, -1)
+    mean = v.mean(-1)
+    m2 = ((v - mean[..., None]) ** 2).sum(-1)
+    pc = part.double().cpu()
+    scale = (m2 / v.shape[-1]).sqrt().clamp_min(1e-3)           # per-chunk std
+    mean_err = float(((pc[..., 0] - mean).abs() / scale).max())
+    m2_err = float(((pc[..., 1] - m2).abs() / m2.clamp_min(1e-6)).max())
+    print(f"[parity] conv gn_partial B{B} {H}^2 {Cin}->{Cout} s{stride} {dt} epilogue={epi_path}: mean err {mean_err:.2e} std, M2 rel err {m2_err:.2e}")
+    assert mean_err < 2e-5 and m2_err < 2e-4
+    # (b) GroupNorm from the partials vs its own statistics pass
+    gm, bt = dev(1 + 0.1 * gen((Cout,), 125)), dev(0.1 * gen((Cout,), 126))
+    g1 = ops.groupnorm(out, ops.empty(tuple(out.shape)), gm, bt, 1e-5, True, partial=part)
+    g2 = ops.groupnorm(out, ops.empty(tuple(out.shape)), gm, bt, 1e-5, True)
+    torch.cuda.synchronize()
+    assert relmax(g1, g2.float().cpu()) < 2.0 ** -7 and rel_rms(g1, g2.float().cpu()) < 5e-4
+    # (e) determinism
+    part2 = ops.empty(shape, torch.float32)
+    ops.conv3x3(dev(x), dev(wp), ops.empty((B, Ho, Ho, Cout)), bias=dev(bias), stride=stride, gn_partial=part2, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(part, part2)
+
+
+# ---------------------------------------------------------------------------------------------------
 # the d = 80 / 160 LDS-DMA attention kernel (attention8.hip, round 5), forced through idf_set_tuning(IDF_TUNE_ATTN8)
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(params=[(1, torch.bfloat16), (1, torch.float16), (2, torch.bfloat16), (3, torch.bfloat16), (4, torch.bfloat16),

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
   __shared__ __attribute__((aligned(16))) unsigned short Kl[2 * KSZ];     // double-buffered: ONE barrier per KV tile
   __shared__ __attribute__((aligned(16))) unsigned short Vl[2 * VSZ];
   __shared__ __attribute__((aligned(16))) unsigned Bl[MASK ? 2 * KVT : 4];  // key mask words of the two staged tiles
+  // O staging of the coalesced epilogue (round 5): wave-private [32 queries][d].  The streaming variants reuse the K ring (dead
+  // behind the last tile's barrier); with resident keys the ring stays live across the workgroup's query blocks -> own buffer.
+  __shared__ __attribute__((aligned(16))) unsigned short Ol[RES ? 4 * 32 * 16 * NKS : 8];
+  static_assert(2 * KSZ >= 4 * 32 * 16 * NKS, "the K ring must hold the four waves' O staging blocks");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -325,7 +329,42 @@ __global__ __launch_bounds__(256, (NKS <= 3 ? IDF_ATTN_MIN_WAVES : 1)) void attn
     l_tot = l_run + __shfl_xor(l_run, 32, 64);
   }
   const float inv = 1.0f / l_tot;
-  if (qrow < p.nq) {
+  // A lane owns ONE query row in 8-byte pieces: stored directly that is up to 20 8-B stores per lane at a 2*ldo-byte lane stride --
+  // 64 separate requests per store instruction, every piece a partial sector: the cross-attention launches (a few MFMAs per query
+  // block) were bound by exactly this store tail (round 5; the d = 40 / 80 / 160 LDS-DMA kernels already store this way).  Now the
+  // wave transposes its 32 x d block through LDS and writes 16 B per lane, consecutive lanes on consecutive chunks of a row.
+  // Needs 16-B-aligned output rows; else (ldo % 8 == 4, legal for idf_attention) the direct 8-B stores.
+  const bool wide = ((p.ldo & 7) == 0) && ((p.sO & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15u) == 0);
+  if (wide) {
+    // (streaming variants: every tile, the last one included, ends with the workgroup barrier -- the K ring is dead here)
+    unsigned short* const ow = (RES ? Ol : Kl) + wave * (32 * 16 * NKS);
+    unsigned short* orow = ow + l31 * d;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int e = mt * 32 + 8 * qd + 4 * hi;
+        if (e < d) {
+          u32x2 pk = {pack2<DT>(o[mt][4 * qd] * inv, o[mt][4 * qd + 1] * inv),
+                      pack2<DT>(o[mt][4 * qd + 2] * inv, o[mt][4 * qd + 3] * inv)};
+          *reinterpret_cast<u32x2*>(orow + e) = pk;
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int q0 = qblk * 128 + wave * 32;
+    unsigned short* const obase = p.out + (size_t)b * p.sO + h * d;
+    const int nch = 4 * d;                            // 16-B chunks of the 32 x d block (dch per row)
+    for (int c = lane; c < nch; c += 64) {
+      const int row = c / dch, col = c - row * dch;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ow + c * 8);
+      if (q0 + row < p.nq) *reinterpret_cast<u32x4*>(obase + (size_t)(q0 + row) * p.ldo + col * 8) = v;
+    }
+    if (RES) {                                        // the staging block is rewritten by this wave's next query block
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if (qrow < p.nq) {
     unsigned short* op = p.out + (size_t)b * p.sO + (size_t)qrow * p.ldo + h * d;
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)

@@ -202,7 +202,8 @@ def measure_roofline(engine, batch, fuser_on=True):
                     "epilogue; gemm_kernel_ring / gemm_kernel_dma 128x128 for small grids and batched launches) + mlp320_kernel (the C = 320 GEGLU "
                     "feed-forwards, both products in one launch)",
             "attention": "attn4_kernel<DT,3,2,1> for d=40 (64 queries/wave, LDS-DMA K / V^T rings, max-free softmax, XCD-aware "
-                         "grid) / attn_kernel for d=80,160 and the 77-key cross-attention"
+                         "grid) / attn8_kernel for d=80,160 (32 queries/wave, LDS-DMA rings, deferred-rescale running max) / "
+                         "attn_kernel for the 77-key cross-attention"
             }.get(name, name)
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     pmc = pmc_traffic(name, batch)
@@ -444,11 +445,11 @@ def main():
                                          ms_per_step=round(leg["ms_per_step"], 2),
                                          note="same workload in the other 16-bit storage type (the reference's GPU path is fp16 "
                                               "autocast, inference.py:94); fp16 parity is 10x tighter and the MFMA rate is the "
-                                              "same; the leg runs a few per cent slower because the d = 40 attention re-bases its "
-                                              "softmax reference far more often in fp16 (attention4.hip RefShift: the largest P of a "
-                                              "query is kept at 2^-1 instead of 2^-7 so that small probabilities stay normal fp16 "
-                                              "numbers, i.e. any score 2 log2-units above the reference sends the wave through the "
-                                              "exact re-base path)")
+                                              "same.  Rounds 2-4 ran this leg 5-6 % behind bf16: the d = 40 attention kept the largest "
+                                              "P of a query at 2^-1 in fp16 (2^-7 in bf16), so any score 2 log2-units above the reference "
+                                              "sent the wave through the exact re-base path; round 5 gives fp16 the same 2^-7 headroom "
+                                              "(attention4.hip RefShift; small P become fp16 denormals, which the conversion produces and "
+                                              "the MFMA consumes exactly)")
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

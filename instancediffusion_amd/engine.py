@@ -165,6 +165,10 @@ class UNetEngine:
         self.heads = model.num_heads
         self.masked_fuser = not getattr(model, "efficient_attention", True)     # attention.py:189
         self.vt_global = os.environ.get("IDF_VT_GLOBAL", "1") != "0"            # A/B knob, see _self_attn
+        # fewest tokens per sample for the fused q | k | v launch.  Round 5: 256 (was 1024) -- at the 16 x 16 level the fused launch
+        # (M32768 N3840 K1280, y read once) replaces the q | k GEMM + the batched 62-%-padded V^T GEMM (2.05 ms per 128-row forward
+        # at 523 TF): 165.9 -> 164.7 ms per forward on one box, 64 no further gain (profiles/r05_vt_min_n_ab.log)
+        self.vt_min_n = int(os.environ.get("IDF_VT_MIN_N", "256"))
         self.use_graphs = use_graphs and self.device.type == "cuda"
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
@@ -576,7 +580,7 @@ class UNetEngine:
         into the projections (``_fold_ln``).  Returns the attention output [B, N, C] (pre out-proj).
         ``vis``: (qbits, kbits0, kbits1) visibility words of the masked gated self-attention, or None."""
         ops = self.ops
-        fused = self.vt_global and N % 64 == 0 and N >= 1024
+        fused = self.vt_global and N % 64 == 0 and N >= self.vt_min_n
         if fused:
             # fused q | k | v projection (round 3): ONE GEMM over the [3C, C] image reads y once; its last C columns are
             # stored TRANSPOSED straight into the batch-interleaved V^T image [C][B][N] (the attention kernel reads sample b

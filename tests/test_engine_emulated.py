@@ -156,10 +156,10 @@ def test_broadcast_mask_stack_is_tokenized_once():
 
 
 def test_fused_qkv_projection_equals_the_two_gemm_form():
-    """At >= 1024 tokens per sample the engine issues ONE q | k | v GEMM whose last C columns land transposed in the
-    batch-interleaved V^T image (``vt_out``, include/idf.h); below, and with IDF_VT_GLOBAL=0, the q | k GEMM plus the
-    transposed-V GEMM it replaced.  Same forward either way (32x32 latent on the 3-level model: the 320-channel level has
-    1024 tokens), also against the CPU oracle; the fused call count is checked."""
+    """From ``engine.vt_min_n`` tokens per sample (round 5: 256; rounds 3-4: 1024) the engine issues ONE q | k | v GEMM whose last C
+    columns land transposed in the batch-interleaved V^T image (``vt_out``, include/idf.h); below, and with IDF_VT_GLOBAL=0, the
+    q | k GEMM plus the transposed-V GEMM it replaced.  Same forward every way (32x32 latent on the 3-level model: the 320-channel
+    level has 1024 tokens, the 640-channel level 256, the last one 64), also against the CPU oracle; the fused call count is checked."""
     from oracle import ref_cpu
     cfg = cases.cfg_for("test_box.yaml", "mid")
     model = build_model(cfg)
@@ -173,7 +173,7 @@ def test_fused_qkv_projection_equals_the_two_gemm_form():
     grounding = GroundingNetInput().prepare(gb)
     outs = []
     with torch.no_grad():
-        for vt_global in (True, False):
+        for vt_global, min_n in ((True, 256), (True, 1024), (False, 256)):
             ops = EmulOps(torch.float32)
             fused_calls = [0]
             real = ops.gemm
@@ -183,14 +183,15 @@ def test_fused_qkv_projection_equals_the_two_gemm_form():
                 return _real(*a, **k)
             ops.gemm = counting
             eng = UNetEngine(model, ops=ops, use_graphs=False)
-            eng.vt_global = vt_global
+            assert eng.vt_min_n == 256                      # the shipped default
+            eng.vt_global, eng.vt_min_n = vt_global, min_n
             cond = eng.prepare_cond(ctx, grounding)
             outs.append(eng.forward_cond(x, t, cond))
-            n_top = sum(1 for p in eng._st_layers() if p["c"] == 320)
-            assert fused_calls[0] == (2 * n_top if vt_global else 0)          # self + gated self-attention per layer
+            n_fused = sum(1 for p in eng._st_layers() if p["c"] == 320 or (p["c"] == 640 and min_n <= 256))
+            assert fused_calls[0] == (2 * n_fused if vt_global else 0)          # self + gated self-attention per layer
         objs, _ = ref_cpu.unifusion(sd, cfg, ref_cpu.prepare_grounding(gb))
         want = ref_cpu.unet_forward(sd, cfg, x, t.long(), ctx, objs)
-    assert cases.rel_rms(outs[0], outs[1]) < 1e-5
+    assert cases.rel_rms(outs[0], outs[2]) < 1e-5 and cases.rel_rms(outs[1], outs[2]) < 1e-5
     assert cases.rel_rms(outs[0], want) < 3e-4
 
 

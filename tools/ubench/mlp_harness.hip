@@ -139,6 +139,9 @@ int main(int argc, char** argv) {
         s12 += (a - b) * (a - b); s2 += b * b;
       }
       printf("    whole output (every 7th element): fused vs two-gemm rel-rms %.3e, non-finite %zu\n", std::sqrt(s12 / s2), bad);
+      unsigned long long fnv = 1469598103934665603ull;            // checksum of the WHOLE fused output: schedule variants must agree bit for bit
+      for (size_t i = 0; i < ho.size(); ++i) { fnv ^= ho[i]; fnv *= 1099511628211ull; }
+      printf("    fused output checksum %016llx\n", fnv);
     }
     // ---- timing
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -96,6 +96,11 @@ __device__ __forceinline__ void dma16_v(const void* addr /* per lane */, unsigne
 // Slot image: [32 rows][64 B], 16-B piece ^= f(row) with f = ((b2 ^ b3) << 1) | (b1 ^ b3 ^ b4) of the row's bits: both access
 // patterns (lane = row with two pieces: "math layout"; 4 lanes per row: "store layout") are bank-conflict-free for
 // ds_read_b128's 16-lane groups and ds_write_b128's 8-lane groups.
+// DEFAULT OFF: measured -0.1 ... -8 % (profiles/r04_big_stage_epilogue.log) -- the ~12 B/clk per CU at which an epilogue
+// drains is not a request-count limit -- so build.sh does not define IDF_EPI_STAGE and the GPU suite does not cover the staged
+// path; it is kept as the A/B build `tools/ubench/big_sched_stage1` measured.  The wave-private 2-KB slots themselves are NOT
+// dead weight: the fused q | k | v projection parks its in-loop LayerNorm statistics there (LNS + VT) and, since round 5, the GST
+// conv epilogue passes its 2 x 160 column totals through them.
 #ifndef IDF_EPI_STAGE
 #define IDF_EPI_STAGE 0
 #endif

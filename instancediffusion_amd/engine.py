@@ -556,9 +556,10 @@ class UNetEngine:
         shape = self.ops.gn_partial_shape(B, HW, C) if (GN_EPI and hasattr(self.ops, "gn_partial_shape")) else None
         return None if shape is None else self.buf(role, shape, torch.float32)
 
-    def _res(self, p, x, emb_all, out_role, gnp=None):
+    def _res(self, p, x, emb_all, out_role, gnp=None, want_out=True):
         """ResBlock (openaimodel.py:237-257).  ``gnp``: partial GroupNorm statistics of x left by its producer, or None.
-        Returns (h, partial statistics of h for the next layer's GroupNorm, or None)."""
+        ``want_out``: the layer that follows normalises this block's output first (ResBlock / SpatialTransformer), so conv2 leaves
+        the statistics too.  Returns (h, partial statistics of h for the next layer's GroupNorm, or None)."""
         ops = self.ops
         B, H, W, Cin = x.shape
         Cout = p["cout"]
@@ -572,7 +573,7 @@ class UNetEngine:
                           bias=p["skip"].b).view(B, H, W, Cout)
         else:
             xs = x
-        p2 = self._gnp("gnp.out", B, H * W, Cout)
+        p2 = self._gnp("gnp.out", B, H * W, Cout) if want_out else None
         return ops.conv3x3(g2, p["conv2"].w, self.buf(out_role, (B, H, W, Cout)), bias=p["conv2"].b, res=xs, gn_partial=p2), p2
 
     def _self_attn(self, a, y, st, B, N, C, kv_extra=None, vis=None):
@@ -689,25 +690,28 @@ class UNetEngine:
         ops.gemm(y, p["proj_out"].w, x.view(M, C), bias=p["proj_out"].b, res=x.view(M, C))
         return x
 
-    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role, dup_st: bool = False, gnp=None):
+    def _run_block(self, layers, h, x_nchw, emb_all, cond, fuser_on, out_role, dup_st: bool = False, gnp=None, next_kind=None):
         """One TimestepEmbedSequential.  ``gnp``: partial GroupNorm statistics of h left by the conv that produced it (or None);
         they are handed from a producing conv to the layer that follows IMMEDIATELY and dropped by anything else -- a
-        SpatialTransformer rewrites its input buffer in place.  Returns (h, partial statistics of h or None)."""
+        SpatialTransformer rewrites its input buffer in place.  ``next_kind``: kind of the first layer of the block that consumes
+        this block's output directly (None: a ScaleU concat or nothing).  Returns (h, partial statistics of h or None)."""
         for j, p in enumerate(layers):
             k = p["kind"]
+            nxt = layers[j + 1]["kind"] if j + 1 < len(layers) else next_kind
+            norm_next = nxt in ("res", "st")                  # the consumer's first op is a GroupNorm of this layer's output
             if k == "conv_in":
                 B, _, H, W = x_nchw.shape
                 h = self.ops.conv_in(x_nchw, p["w"], p["b"], self.buf(out_role, (B, H, W, p["w"].shape[0])))
                 gnp = None
             elif k == "res":
-                h, gnp = self._res(p, h, emb_all, out_role, gnp)
+                h, gnp = self._res(p, h, emb_all, out_role, gnp, want_out=norm_next)
             elif k == "st":
                 h = self._st(p, h, cond, fuser_on, dup=dup_st, gnp=gnp)
                 gnp = None
             elif k == "down":
                 B, H, W, C = h.shape
                 Ho, Wo = (H + 1) // 2, (W + 1) // 2
-                gnp = self._gnp("gnp.out", B, Ho * Wo, C)
+                gnp = self._gnp("gnp.out", B, Ho * Wo, C) if norm_next else None
                 h = self.ops.conv3x3(h, p["conv"].w, self.buf(out_role, (B, Ho, Wo, C)), bias=p["conv"].b, stride=2, gn_partial=gnp)
             elif k == "up":
                 B, H, W, C = h.shape
@@ -734,15 +738,16 @@ class UNetEngine:
         hs = []
         h, gnp = None, None
         for i, layers in enumerate(self.in_blocks):
+            nk = (self.in_blocks[i + 1] if i + 1 < len(self.in_blocks) else self.mid_block)[0]["kind"]
             if hoist and i == 0:
                 h, gnp = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in0.half")
                 hs.append(self._dup(h, "in0"))
                 continue
             if hoist and i == 1:
-                h, gnp = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in1.half", dup_st=True, gnp=gnp)
+                h, gnp = self._run_block(layers, h, x[:n], emb_all[:n], cond, fuser_on, "in1.half", dup_st=True, gnp=gnp, next_kind=nk)
                 hs.append(h)
                 continue
-            h, gnp = self._run_block(layers, h, x, emb_all, cond, fuser_on, f"in{i}", gnp=gnp)
+            h, gnp = self._run_block(layers, h, x, emb_all, cond, fuser_on, f"in{i}", gnp=gnp, next_kind=nk)
             hs.append(h)
         h, gnp = self._run_block(self.mid_block, h, x, emb_all, cond, fuser_on, "mid", gnp=gnp)
         for i, layers in enumerate(self.out_blocks):

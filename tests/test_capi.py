@@ -101,6 +101,26 @@ def test_argument_validation_without_gpu():
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ldo=324)), None) == -2                 # 16-B row alignment
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ln_stats=0x20004)), None) == -2
     assert lib.idf_mlp_geglu(ctypes.byref(mlp_args(ldw2=640)), None) == -1                # rows of W2 shorter than 4C
+    # GroupNorm partial statistics (ABI 5): the conv's gn_partial contract and the split GroupNorm entry points validate before any launch
+    def conv_args(**kw):
+        c = _lib.ConvArgs(x=0x10000, W=0x20000, out=0x30000, bias=0x40000, B=2, Hin=16, Win=16, Cin=320, Cout=320, stride=1,
+                          upsample=0, ldx=320, ldo=320, epi=_lib.EPI_BIAS, dtype=0, gn_partial=0x50000)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+    assert lib.idf_conv3x3(ctypes.byref(conv_args(Hin=10, Win=10)), None) == -1           # 100 output rows per sample: not whole 64-row chunks
+    assert lib.idf_conv3x3(ctypes.byref(conv_args(Cout=336, ldo=336)), None) == -1        # 336 channels: not 32 groups
+    assert lib.idf_conv3x3(ctypes.byref(conv_args(ldo=640)), None) == -1                  # the output must be the dense NHWC matrix
+    assert lib.idf_conv3x3(ctypes.byref(conv_args(epi=_lib.EPI_BIAS | _lib.EPI_OUT_F32)), None) == -1
+    assert lib.idf_conv3x3(ctypes.byref(conv_args(gn_partial=0x50004)), None) == -2       # 8-B aligned (mean, M2) pairs
+    assert lib.idf_groupnorm_stats(None, 0x1000, 1, 64, 320, 1, 0, None) == -1
+    assert lib.idf_groupnorm_stats(0x10000, 0x20000, 1, 64, 330, 1, 0, None) == -1         # C % 32
+    assert lib.idf_groupnorm_stats(0x10000, 0x20000, 1, 64, 320, 0, 0, None) == -1         # nchunks >= 1
+    assert lib.idf_groupnorm_stats(0x10000, 0x20000, 1, 64, 320, 65, 0, None) == -1        # more chunks than rows
+    assert lib.idf_groupnorm_stats(0x10008, 0x20000, 1, 64, 320, 1, 0, None) == -2
+    assert lib.idf_groupnorm_apply(0x10000, 0x20000, 0x30000, 0x40000, None, 1, 64, 320, 1, 1e-5, 1, 0, None) == -1
+    assert lib.idf_groupnorm_apply(0x10000, 0x20008, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 0, None) == -2
+    assert lib.idf_groupnorm_apply(0x10000, 0x20000, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 7, None) == -3
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
     assert lib.idf_set_tuning(5, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
     # round 5 (ABI 5): the d = 80 / 160 LDS-DMA attention kernel's knob and launch counter

@@ -294,3 +294,43 @@ def test_paired_flag_on_a_batch_that_is_not_a_guidance_pair_is_rejected(monkeypa
             eng.forward_cond(x2, torch.cat([t, t]), pair, paired=True)
         # without the flag the same batch is an ordinary 4-row forward
         assert torch.isfinite(eng.forward_cond(x2, torch.cat([t, t]), pair)).all()
+
+
+def test_groupnorm_partials_travel_from_the_producing_conv_to_the_next_groupnorm(monkeypatch):
+    """Round 5: a 3x3 conv whose output feeds a GroupNorm leaves that GroupNorm's partial statistics (idf_conv3x3 gn_partial) and the
+    GroupNorm only normalises.  The engine hands the partials from a producing conv to the layer that follows IMMEDIATELY -- ResBlock
+    conv1 -> its second GroupNorm, ResBlock conv2 -> the SpatialTransformer's norm / the next ResBlock's first GroupNorm, Downsample ->
+    the next ResBlock -- and drops them behind anything else: a SpatialTransformer rewrites its input buffer in place, and the decoder's
+    first GroupNorm reads the ScaleU concat.  Checked: every partial a conv leaves is consumed by exactly one GroupNorm, the GroupNorms
+    behind a SpatialTransformer / a concat run their own statistics pass, and the forward equals the IDF_GN_EPI=0 one to fp32 rounding."""
+    from instancediffusion_amd import engine as engine_mod, synth
+    cfg = cases.cfg_for("test_box.yaml", "mid")
+    model = build_model(cfg)
+    g = torch.Generator().manual_seed(35)
+    gb = synth.make_grounding_batch(2, synth.random_boxes(3, g), g)
+    x = torch.randn(2, 4, 32, 32, generator=g)
+    ctx = torch.randn(2, 77, 768, generator=g)
+    t = torch.tensor([700.0, 300.0])
+    grounding = GroundingNetInput().prepare(gb)
+    outs, counts = [], []
+    with torch.no_grad():
+        for epi in (True, False):
+            monkeypatch.setattr(engine_mod, "GN_EPI", epi)
+            ops = EmulOps(torch.float32)
+            eng = UNetEngine(model, ops=ops, use_graphs=False)
+            cond = eng.prepare_cond(ctx, grounding)
+            c0 = dict(ops.calls)
+            outs.append(eng.forward_cond(x, t, cond))
+            counts.append({k: ops.calls.get(k, 0) - c0.get(k, 0) for k in ("conv3x3_gn_partial", "groupnorm_from_partial", "groupnorm")})
+    on, off = counts
+    assert off["conv3x3_gn_partial"] == 0 and off["groupnorm_from_partial"] == 0
+    assert on["groupnorm"] == off["groupnorm"]                                     # the same GroupNorms run either way
+    assert on["conv3x3_gn_partial"] == on["groupnorm_from_partial"] > 0            # produced exactly where consumed
+    # GroupNorms that keep their own pass: the first ResBlock's (behind conv_in), the ones behind a SpatialTransformer, the decoder's
+    # first (ScaleU concat) and the output GroupNorm
+    n_res = sum(1 for blk in list(eng.in_blocks) + [eng.mid_block] + list(eng.out_blocks) for p in blk if p["kind"] == "res")
+    n_st_after_res = sum(1 for blk in list(eng.in_blocks) + [eng.mid_block] + list(eng.out_blocks)
+                         for a, b in zip(blk, blk[1:]) if a["kind"] == "res" and b["kind"] == "st")
+    assert on["groupnorm_from_partial"] >= n_res + n_st_after_res                  # every gn2 + every norm right behind a ResBlock
+    assert on["groupnorm_from_partial"] < on["groupnorm"]
+    assert cases.rel_rms(outs[0], outs[1]) < 2e-5        # fp32 summation order of the statistics only (64-row chunk partials vs F.group_norm)

@@ -136,10 +136,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const AttnParams p, c
 #ifndef IDF_ATTN8_FMA_SCALE
   const float c = 1.0f;
 #else
-  float c = p.scale_log2;
-#ifdef IDF_ATTN8_CVGPR
-  asm volatile("" : "+v"(c));
-#endif
+  const float c = p.scale_log2;
 #endif
 
   const int T0 = (p.n[0] + KVT - 1) / KVT;

@@ -67,7 +67,12 @@ const char* idf_build_info(void);
  *   (d in {24,40,56}, n0 % 8 == n1 % 8 == 0, no mask) the 64-queries-per-wave LDS-DMA kernel (attention4.hip: max-free
  *   softmax with the reference value folded into the K.Q^T MFMA, K fragments read one tile ahead, XCD-aware 1-D grid) as two
  *   4-wave workgroups per CU (256 queries each); 2 = the same kernel as one 8-wave workgroup per 512 queries; 3 = mode 1
- *   with the plain block order (A/B of the XCD mapping).  Initial value: env IDF_ATTN2 or the default (1).
+ *   with the plain block order (A/B of the XCD mapping); 4 / 5 (round 6, d = 40 only; other head dims run as mode 1) = the
+ *   asm-scheduled stream of attention4w.hip -- every MFMA, v_exp, v_cvt_pk and LDS read of the tile loop in program order,
+ *   accumulators / Q / V^T fragments in asm-owned AGPRs, no per-tile overflow guard (one finiteness check per block, exact
+ *   rerun otherwise) -- with 128 queries per wave and one wave per SIMD (4) or 64 queries per wave and two 4-wave workgroups
+ *   per CU (5; the default: +6..8 % over mode 1 in isolation, -1.2 % on a 128-row forward).  Results of modes 1, 4, 5 are
+ *   bit-identical unless a re-base / rerun path is taken.  Initial value: env IDF_ATTN2 or the default (5).
  *   IDF_TUNE_GEMM_RING (round 4): the launches the persistent kernel declines (small batches: every GEMM / conv of a 2-row
  *   forward) go to the LATENCY kernel -- the 128 x {128,64} tiles of the default small-tile kernels with a 4-5-stage LDS-DMA
  *   ring that has its K-tiles in flight from the first instruction instead of one at a time -- when their tile grid has at most

@@ -437,7 +437,7 @@ int idf_attn2_mode() {
     // the same range idf_set_tuning accepts
     const char* e = getenv("IDF_ATTN2");
     const int v = e ? atoi(e) : IDF_ATTN2_DEFAULT;
-    g_attn2_mode = (v < 0 || v > 3) ? IDF_ATTN2_DEFAULT : v;
+    g_attn2_mode = (v < 0 || v > 5) ? IDF_ATTN2_DEFAULT : v;
   }
   return g_attn2_mode;
 }
@@ -471,6 +471,10 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
     p.kbits[1] = (const unsigned*)(a->n1 > 0 ? a->kbits1 : a->kbits0); p.sKb[1] = a->n1 > 0 ? a->strideKb1 : a->strideKb0;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (!a->qbits && idf_attn2_mode() >= 4) {
+    const int rc = idf_launch_attn4w(p, a->B, a->dtype, idf_attn2_mode() == 4 ? 4 : 2, s);
+    if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }
+  }
   if (!a->qbits && idf_attn2_mode() > 0) {
     const int rc = idf_launch_attn4(p, a->B, a->dtype, s);
     if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }

@@ -26,19 +26,22 @@ struct AttnParams {
 // qualifies, as two 4-wave workgroups per CU (256 queries each; default); 2 = as ONE 8-wave workgroup per 512 queries (every
 // K / V^T tile shared by eight waves: 1.4 LDS-DMA instructions per wave and tile instead of 2.75 -- +1 % in isolation,
 // -3 % inside the forward, where the two independent workgroups of a CU overlap better: profiles/r03_attn_ab*_B64.log,
-// r03_shape_profile_B64_attn{1,2}.log); 3 = mode 1 with the plain block order (A/B of the XCD mapping).
+// r03_shape_profile_B64_attn{1,2}.log); 3 = mode 1 with the plain block order (A/B of the XCD mapping); 4 / 5 = attention4w.hip
+// (round 6: the asm-scheduled stream, d = 40 only) with 128 queries per wave on one wave per SIMD / 64 on two (default 5).
 // The round-1 / round-2 variants this kernel replaced (attention2.hip: classic / lazy / software-pipelined online softmax;
 // attention5.hip: 8-wave ping-pong form) were measured slower and live under tools/ubench/archive/ with their logs in
 // profiles/r02_attn_*.
 #define IDF_ATTN2_UNSUPPORTED (-100)
 #ifndef IDF_ATTN2_DEFAULT
-#define IDF_ATTN2_DEFAULT 1
+#define IDF_ATTN2_DEFAULT 5
 #endif
 #include <atomic>
 extern std::atomic<long long> idf_stat_attn2_launches;   // process-global launch counter (idf_get_stat)
 int idf_attn2_mode();
 int idf_attn2_set_mode(int v);
 int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
+// one-wave-per-SIMD form of the d = 40 kernel (attention4w.hip, round 6): 128 queries per wave, asm-scheduled stream
+int idf_launch_attn4w(const idfattn::AttnParams& p, int B, int dtype, int ng /* 4: one wave per SIMD, 2: two */, hipStream_t s);
 // 32-queries-per-wave LDS-DMA kernel for d in {80, 160} (attention8.hip, round 5): K / V^T rings by LDS-DMA, deferred-rescale
 // running max, XCD-aware 1-D grid.  Mode (idf_set_tuning(IDF_TUNE_ATTN8), env IDF_ATTN8): 0 = off (attention.hip's register-staged
 // kernel); 1 = on (d = 80: two 4-wave workgroups per CU with the K fragments read one tile ahead; d = 160: one 8-wave workgroup

@@ -122,14 +122,14 @@ def test_argument_validation_without_gpu():
     assert lib.idf_groupnorm_apply(0x10000, 0x20008, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 0, None) == -2
     assert lib.idf_groupnorm_apply(0x10000, 0x20000, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 7, None) == -3
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
-    assert lib.idf_set_tuning(5, 0) == -1 and lib.idf_set_tuning(1, 4) == -1 and lib.idf_set_tuning(0, 4) == -1
+    assert lib.idf_set_tuning(5, 0) == -1 and lib.idf_set_tuning(1, 6) == -1 and lib.idf_set_tuning(0, 4) == -1      # (round 6: attention modes 4 / 5 = attention4w.hip)
     # round 5 (ABI 5): the d = 80 / 160 LDS-DMA attention kernel's knob and launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 7) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 3)
     assert prev in range(7) and lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, prev) == 3
     assert lib.idf_get_stat(_lib.IDF_STAT_ATTN8_LAUNCHES) == 0
     prev = lib.idf_set_tuning(1, 2)
-    assert prev in (0, 1, 2, 3) and lib.idf_set_tuning(1, prev) == 2
+    assert prev in (0, 1, 2, 3, 4, 5) and lib.idf_set_tuning(1, prev) == 2
     # round 4: tile-count threshold of the latency kernel (0 = never), and its launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 77)
@@ -165,11 +165,26 @@ def test_stale_tuning_values_in_the_environment_fall_back_to_the_default():
     env = dict(os.environ, IDF_ATTN2="9", IDF_GEMM_BIG="-5", IDF_GEMM_RING="-3", IDF_BIG_MIN_EFF="250")
     out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-500:]
-    assert out.stdout.strip().splitlines()[-1] == "1 1 256 50", out.stdout        # the library defaults
+    assert out.stdout.strip().splitlines()[-1] == "5 1 256 50", out.stdout        # the library defaults
     # in-range values ARE taken from the environment
     env = dict(os.environ, IDF_GEMM_RING="0", IDF_BIG_MIN_EFF="80")
     out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].split()[2:] == ["0", "80"], out.stdout + out.stderr[-300:]
+
+
+def test_attention4w_asm_owned_registers_are_left_alone_by_the_compiler():
+    """attention4w.hip keeps its accumulators, Q and V^T fragments in AGPRs named in inline asm.  The register allocator knows
+    them only as clobbers: a compiler-generated v_accvgpr_* (an AGPR used as VGPR spill space) or any scratch access inside the
+    kernel would silently corrupt them (it happened: 7 VGPRs spilled into a0..a6 in the first two-waves-per-SIMD build).
+    tools/check_attn4w_isa.py compiles the file with the library's flags and scans the listing of all four instantiations."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_attn4w_isa", os.path.join(REPO, "tools", "check_attn4w_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.check()
+    assert len(rep) == 4, sorted(rep)
+    for name, r in rep.items():
+        assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 50, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
 
 
 def test_schema_matches_reference():

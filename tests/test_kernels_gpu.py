@@ -749,9 +749,11 @@ def test_gemm_ring_matches_small_kernels_bitwise_on_exact_data(ops, ring):
 # ---------------------------------------------------------------------------------------------------
 # the 64-queries-per-wave attention kernel (attention4.hip), forced through idf_set_tuning
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3], ids=["v4-4waves", "v4-8waves", "v4-4waves-plain-grid"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["v4-4waves", "v4-8waves", "v4-4waves-plain-grid", "v4w-1wave-per-simd", "v4w-2waves-per-simd"])
 def attn2(request):
-    """The 64-queries-per-wave LDS-DMA kernel (attention4.hip) in its two block orders; yields its launch counter."""
+    """The 64-queries-per-wave LDS-DMA kernel (attention4.hip) in its two block orders and the asm-scheduled stream of
+    attention4w.hip (round 6; d = 40 only -- other head dims fall through to attention4.hip) with 128 / 64 queries per wave;
+    yields the launch counter."""
     from instancediffusion_amd import _lib
     lib = _lib.load()
     prev = lib.idf_set_tuning(1, request.param)
@@ -1191,15 +1193,17 @@ def test_gemm_out_stats(ops):
 
 
 
-@pytest.fixture(params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.fixture(params=[(torch.bfloat16, 1), (torch.float16, 1), (torch.bfloat16, 4), (torch.float16, 4), (torch.bfloat16, 5), (torch.float16, 5)],
+                ids=["bf16", "fp16", "bf16-v4w", "fp16-v4w", "bf16-v4w-2waves", "fp16-v4w-2waves"])
 def attn4(request):
-    """attention4.hip forced through idf_set_tuning, in both storage types."""
+    """attention4.hip (mode 1) / attention4w.hip (modes 4, 5) forced through idf_set_tuning, in both storage types."""
     from instancediffusion_amd import _lib
     from instancediffusion_amd.ops import HipOps
     lib = _lib.load()
-    prev = lib.idf_set_tuning(1, 1)
+    dt, mode = request.param
+    prev = lib.idf_set_tuning(1, mode)
     start = lib.idf_get_stat(1)
-    yield HipOps(request.param), request.param, (lambda: lib.idf_get_stat(1) - start)
+    yield HipOps(dt), dt, (lambda: lib.idf_get_stat(1) - start)
     lib.idf_set_tuning(1, prev)
 
 

@@ -81,6 +81,7 @@ struct Lib {
   int (*attention)(const idf_attn_args*, void*);
   int (*set_tuning)(int, int);
   int (*trace_read)(unsigned long long*);          // only in a -DIDF_ATTN_TRACE build of the library
+  int (*trace4w_read)(unsigned long long*);        // only in a -DIDF_ATTN4W_TRACE build
 };
 
 struct Shape { const char* name; int N, d, n0, n1; };
@@ -113,6 +114,7 @@ int main(int argc, char** argv) {
     l.attention = (int (*)(const idf_attn_args*, void*))dlsym(l.h, "idf_attention");
     l.set_tuning = (int (*)(int, int))dlsym(l.h, "idf_set_tuning");
     l.trace_read = (int (*)(unsigned long long*))dlsym(l.h, "idf_attn_trace_read");
+    l.trace4w_read = (int (*)(unsigned long long*))dlsym(l.h, "idf_attn4w_trace_read");
     if (!l.attention || !l.set_tuning) { fprintf(stderr, "%s: missing symbols\n", argv[i]); return 2; }
     libs.push_back(l);
   }
@@ -182,7 +184,16 @@ int main(int argc, char** argv) {
         float er[3]; hipMemcpy(er, err, 12, hipMemcpyDeviceToHost);
         printf("%-11s d=%-3d keys %4d+%-3d lib %zu knob %d mode %d: rc %d %8.1f us %7.1f TF  csum %016llx  maxerr %.2e relrms %.2e\n", sh.name, sh.d,
                sh.n0, sh.n1, li, knob, m, rc, best * 1e3, flops / (best * 1e-3) / 1e12, cs, er[0], sqrt(er[1] / (er[2] + 1e-30)));
-        if (libs[li].trace_read && sh.d == 40 && sh.n0 > 77 && m >= 1) {
+        if (libs[li].trace4w_read && sh.d == 40 && sh.n0 > 77 && m == 4) {
+          unsigned long long tr[4][4];
+          if (libs[li].trace4w_read(&tr[0][0]) == 0)
+            for (int w = 0; w < 4; ++w) {
+              const double nt = (double)tr[w][3];
+              if (nt > 0) printf("    wave %d, per tile of the stream (%.0f tiles; 1792 cycles of MFMA each): block0 %.0f block1 %.0f wait+barrier %.0f = %.0f\n", w, nt,
+                                 tr[w][0] / nt, tr[w][1] / nt, tr[w][2] / nt, (tr[w][0] + tr[w][1] + tr[w][2]) / nt);
+            }
+        }
+        if (libs[li].trace_read && sh.d == 40 && sh.n0 > 77 && m >= 1 && m != 4) {
           unsigned long long tr[2][10];
           if (libs[li].trace_read(&tr[0][0]) == 0) {
             const char* seg[9] = {"dma", "qk", "exp0", "pv0", "exp1", "kfrag", "pv1", "wait+bar", "check"};

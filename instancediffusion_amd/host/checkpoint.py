@@ -196,4 +196,5 @@ def load_model_ckpt(ckpt_path: str, args, device):
     autoencoder.load_state_dict(saved_ckpt["autoencoder"])
     text_encoder.load_state_dict(saved_ckpt["text_encoder"], strict=False)
     diffusion.load_state_dict(saved_ckpt["diffusion"])
+    model.ckpt_path = ckpt_path          # UNetModel.first_conv_file looks next to the checkpoint for the SD first-conv file
     return model, autoencoder, text_encoder, diffusion, config

@@ -73,6 +73,12 @@ class _PLMSBase(object):
     def _uncond(self, uc: torch.Tensor):
         return self.engine.prepare_cond(uc, self.model.grounding_tokenizer_input.get_null_input(batch=uc.shape[0]))
 
+    def _check_first_conv(self, alphas):
+        """The alpha schedule reaches 0 (default alpha_type [0.8, 0, 0.2]: at step 40 of 50) -> the model will swap its first
+        conv for Stable Diffusion's (openaimodel.py:469-480) and needs that 48-KB file: find out NOW, not 40 steps in."""
+        if alphas is not None and any(a == 0 for a in alphas) and hasattr(self.model, "check_first_conv_available"):
+            self.model.check_first_conv_available()
+
     def _apply_alpha(self, alphas, i):
         """plms.py:90-94: per-step gate + first-conv swap."""
         if alphas is not None:
@@ -144,6 +150,7 @@ class PLMSSampler(_PLMSBase):
         time_range = np.flip(self.ddim_timesteps)
         total = self.ddim_timesteps.shape[0]
         alphas = self.alpha_generator_func(len(time_range)) if self.alpha_generator_func is not None else None
+        self._check_first_conv(alphas)
         old_eps: list = []
         for i, step in enumerate(time_range):
             self._apply_alpha(alphas, i)
@@ -208,6 +215,7 @@ class PLMSSamplerInst(_PLMSBase):
         time_range = np.flip(self.ddim_timesteps)
         total = self.ddim_timesteps.shape[0]
         alphas = self.alpha_generator_func(len(time_range)) if self.alpha_generator_func is not None else None
+        self._check_first_conv(alphas)
         mis_step = int(total * self.mis)
 
         # ---------------- work split (decided BEFORE any conditioning is built) ---------------------------------

@@ -162,6 +162,37 @@ class UNetModel(nn.Module):
         """Call after mutating parameters in place: the engine re-packs its bf16 weight images lazily."""
         self._engine = None
 
+    def first_conv_file(self):
+        """Where the SD first-conv weights (openaimodel.py:473-476: a 48-KB ``{weight, bias}`` file the reference repository ships
+        under ``pretrained/``) are looked for: the reference's cwd-relative path first, then ``$IDF_PRETRAINED_DIR``, then
+        ``pretrained/`` next to (and the directory of) the checkpoint this model was loaded from (``self.ckpt_path``, set by
+        ``utils.checkpoint.load_model_ckpt``), then this repository's own ``pretrained/``.  Returns the first existing path,
+        else raises FileNotFoundError naming every place tried."""
+        import os
+        name = "SD_v1_5_input_conv_weight_bias.pth" if self.sd_v1_5 else "SD_input_conv_weight_bias.pth"
+        tried = [os.path.join("pretrained", name)]
+        if os.environ.get("IDF_PRETRAINED_DIR"):
+            tried.append(os.path.join(os.environ["IDF_PRETRAINED_DIR"], name))
+        ck = getattr(self, "ckpt_path", None)
+        if ck:
+            d = os.path.dirname(os.path.abspath(ck))
+            tried += [os.path.join(d, "pretrained", name), os.path.join(d, name)]
+        tried.append(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "pretrained", name))
+        for t in tried:
+            if os.path.isfile(t):
+                return t
+        raise FileNotFoundError(
+            f"{name} not found (tried: {', '.join(tried)}).  The samplers swap the UNet's first conv for Stable Diffusion's own "
+            "as soon as the gated-self-attention gate alpha reaches 0 (openaimodel.py:469-480); the file ships with the reference "
+            "repository under pretrained/ -- copy it there, next to the checkpoint, or point IDF_PRETRAINED_DIR at its directory "
+            "(or set model.first_conv_sd_override = {'weight': ..., 'bias': ...}).")
+
+    def check_first_conv_available(self):
+        """Fail BEFORE a sampling run instead of at the step where alpha first reaches 0 (step 40 of 50 with the default
+        alpha_type [0.8, 0, 0.2]): called by the samplers when their alpha schedule contains a 0."""
+        if self.first_conv_restorable and self.first_conv_sd_override is None and not getattr(self, "_first_conv_swapped", False):
+            self.first_conv_file()
+
     def restore_first_conv_from_SD(self):
         """openaimodel.py:469-480: swap input_blocks[0][0] for the SD-1.5 first conv (never undone).
         The reference re-reads the 48 KB file on EVERY alpha==0 step; here the swap is idempotent."""
@@ -172,9 +203,7 @@ class UNetModel(nn.Module):
         if self.first_conv_sd_override is not None:
             sdw = self.first_conv_sd_override
         else:
-            name = "pretrained/SD_v1_5_input_conv_weight_bias.pth" if self.sd_v1_5 else \
-                "pretrained/SD_input_conv_weight_bias.pth"
-            sdw = torch.load(name, map_location="cpu")      # cwd-relative, as in the reference
+            sdw = torch.load(self.first_conv_file(), map_location="cpu", weights_only=True)
         old = self.input_blocks[0][0]
         self.first_conv_state_dict = {k: v.detach().clone() for k, v in old.state_dict().items()}
         new = Conv(self.in_channels, self.model_channels, 3)

@@ -1,6 +1,6 @@
 """Generate golden vectors from the UNMODIFIED reference (/root/reference) -- builder container only.
 
-TEST INFRASTRUCTURE.  Run:  ``python oracle/make_golden.py [--only tiny|full|all]``
+TEST INFRASTRUCTURE.  Run:  ``python oracle/make_golden.py [--only tiny|full|all|full_s50|full_c5|full_c2|...]``
 Writes small fixtures into ``tests/golden/`` (committed), because /root/reference does not exist on the GPU
 box.  The reference modules are imported as-is with three process-local shims:
   1. stub ``timm.models.layers`` / ``timm.models.registry`` (convnext.py:12-13 imports; timm not installed)
@@ -689,6 +689,35 @@ def gen_clip_case(tag="clip_text"):
         sys.modules.pop("ldm.modules.encoders.modules", None)
 
 
+@torch.no_grad()
+def gen_full_c2(tag="full_box_c2_s50", S=50, alpha_type=(0.8, 0.0, 0.2)):
+    """BASELINE config 2 at full size: the 1.228 B-parameter UNet, the C1 demo boxes, ONE image, Multi-instance Sampler OFF --
+    the unmodified reference ``PLMSSampler`` (plms.py:72-113), S = 50, CFG 7.5, alpha [0.8, 0, 0.2] (the first-conv swap at
+    step 40 included): 102 full-size CPU forwards (~5 min on 8 cores)."""
+    print(f"[golden] {tag}", flush=True)
+    cfg = load_cfg("test_box.yaml", "full")
+    model, gi, diffusion, schema, synth = build(cfg)
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = torch.Generator().manual_seed(1234)
+    bx = torch.tensor(synth.C1_BOXES)
+    gb = synth.make_grounding_batch(1, bx, g)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    context = torch.randn(1, 77, 768, generator=g)
+    uc = torch.randn(1, 77, 768, generator=g)
+    grounding = gi.prepare(gb)
+    patch_first_conv(model, synth.synth_first_conv_sd())
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=list(alpha_type)),
+                          set_alpha_scale=ref_set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=context, grounding_input=grounding)
+    out = {"meta": dict(tag=tag, cfg="test_box.yaml", variant="full", alpha_type=list(alpha_type), latent=64, n_boxes=int(bx.shape[0]),
+                        batch=1, boxes="c1", with_scribbles=False, with_polygons=False, with_segs=False, S=S, mis=0.0, n_inst=0,
+                        seg_size=512, x_fp=fp(x), ctx_fp=fp(context))}
+    out["plms"] = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5).clone()
+    out["plms_timesteps"] = [int(v) for v in sampler.ddim_timesteps]
+    os.chdir(REF)
+    torch.save(out, os.path.join(GOLD, f"{tag}.pt"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -720,6 +749,15 @@ def main():
         gen_case("tiny_point_s5", "test_point.yaml", "tiny", 16, 3, 1, alpha_type=(1, 0, 0))
         gen_case("tiny_scribble_s5", "test_scribble.yaml", "tiny", 16, 3, 1, with_scribbles=True, with_polygons=True,
                  with_segs=True, alpha_type=(1, 0, 0))
+    if args.only in ("full_c5",):
+        # C5 at its stated size (round 6): the full model, 64x64 latent, batch 4, N = 8 -- test_point.yaml (only the point tokens
+        # live) and test_scribble.yaml (nothing dropped: live scribbles through the 768 + 1280 -> 3072 MLP, polygons, ConvNeXt
+        # mask tokens); forwards only (cond / uncond / gate scale 0.3)
+        gen_case("full_point_c5", "test_point.yaml", "full", 64, 8, 4, samplers=False)
+        gen_case("full_scribble_c5", "test_scribble.yaml", "full", 64, 8, 4, with_scribbles=True, with_polygons=True,
+                 with_segs=True, samplers=False)
+    if args.only in ("full_c2",):           # 102 full-model forwards on CPU (~5 min on 8 cores): not part of "all"
+        gen_full_c2()
     if args.only in ("all", "c4"):
         # C4 at its stated size: test_mask.yaml, 96x96 latent (768x768), 12 instance masks with segs + polygons
         gen_case("full_mask_c4", "test_mask.yaml", "full", 96, 12, 1, with_polygons=True, with_segs=True, samplers=False)

@@ -304,3 +304,54 @@ def test_clip_text_encoder_forward_matches_reference_golden():
 def test_clip_text_encoder_forward_matches_reference_golden_gpu():
     pytest.importorskip("transformers")
     _clip_vs_golden("cuda")
+
+
+def test_first_conv_file_is_found_next_to_the_checkpoint_or_fails_before_sampling(tmp_path, monkeypatch):
+    """``restore_first_conv_from_SD`` (openaimodel.py:469-480) reads ``pretrained/SD_v1_5_input_conv_weight_bias.pth``
+    relative to the cwd; a run from this tree used to die at the first alpha == 0 step (40 of 50).  Now the file is searched in
+    the cwd, ``$IDF_PRETRAINED_DIR``, next to the checkpoint and in the repository, and a sampler whose alpha schedule reaches 0
+    asks for it BEFORE the first step."""
+    from functools import partial
+    import torch
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from instancediffusion_amd.host.alpha import alpha_generator, set_alpha_scale
+    from instancediffusion_amd.host.config import unet_kwargs_from_cfg
+    from instancediffusion_amd.host.samplers import PLMSSampler
+    from tests import cases
+    with torch.device("meta"):
+        m = UNetModel(**unet_kwargs_from_cfg(cases.cfg_for("test_box.yaml", "full")))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("IDF_PRETRAINED_DIR", raising=False)
+    import instancediffusion_amd.host.unet as unet_mod
+    monkeypatch.setattr(unet_mod.os.path if hasattr(unet_mod, "os") else __import__("os").path, "isfile",
+                        lambda p, _real=__import__("os").path.isfile: _real(p) and str(tmp_path) in os.path.abspath(p))
+    with pytest.raises(FileNotFoundError) as e:
+        m.first_conv_file()
+    assert "IDF_PRETRAINED_DIR" in str(e.value) and "pretrained" in str(e.value)
+
+    class _Diff:
+        num_timesteps = 1000
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2
+        alphas_cumprod = torch.cumprod(1 - betas, 0)
+        alphas_cumprod_prev = torch.cat([torch.ones(1), alphas_cumprod[:-1]])
+    s = PLMSSampler(_Diff(), m, alpha_generator_func=partial(alpha_generator, type=[0.8, 0.0, 0.2]), set_alpha_scale=set_alpha_scale)
+    with pytest.raises(FileNotFoundError):
+        s._check_first_conv(alpha_generator(50, type=[0.8, 0.0, 0.2]))           # reaches 0 at step 40: asks now
+    s._check_first_conv(alpha_generator(50, type=[1.0, 0.0, 0.0]))               # never 0: nothing needed
+    m.first_conv_sd_override = dict(weight=torch.zeros(320, 4, 3, 3), bias=torch.zeros(320))
+    s._check_first_conv(alpha_generator(50, type=[0.8, 0.0, 0.2]))               # an in-memory override satisfies it
+    m.first_conv_sd_override = None
+    # next to the checkpoint
+    ck = tmp_path / "weights" / "instancediffusion_sd15.pth"
+    (tmp_path / "weights" / "pretrained").mkdir(parents=True)
+    f = tmp_path / "weights" / "pretrained" / "SD_v1_5_input_conv_weight_bias.pth"
+    torch.save(dict(weight=torch.zeros(320, 4, 3, 3), bias=torch.zeros(320)), f)
+    m.ckpt_path = str(ck)
+    assert os.path.samefile(m.first_conv_file(), f)
+    s._check_first_conv(alpha_generator(50, type=[0.8, 0.0, 0.2]))
+    # the environment variable
+    m.ckpt_path = None
+    with pytest.raises(FileNotFoundError):
+        m.first_conv_file()
+    monkeypatch.setenv("IDF_PRETRAINED_DIR", str(tmp_path / "weights" / "pretrained"))
+    assert os.path.samefile(m.first_conv_file(), f)

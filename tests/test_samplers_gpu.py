@@ -133,6 +133,15 @@ def test_c5_point_scribble_samplers_fp16(tag):
     _run_mis(tag, torch.float16)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_full_model_c2_plms_s50_matches_reference(dtype):
+    """BASELINE config 2 at full size (the MIS-off trajectory was pinned on the reduced variants only): the
+    1.228 B-parameter UNet, the C1 demo boxes, ONE image, Multi-instance Sampler off -- golden = the unmodified reference
+    ``PLMSSampler`` (plms.py:72-113), S = 50, CFG 7.5, alpha [0.8, 0, 0.2] incl. the first-conv swap at step 40: 102 chained
+    2-row forwards (the small-batch kernels: latency kernel, split-K, 128^2 fallbacks)."""
+    _run_plms("full_box_c2_s50", dtype)
+
+
 def test_mis_crop_and_paste_on_gpu_vs_oracle():
     """The opt-in crop-and-paste merge (plms_instance.py:112-132, hard-coded off in the reference :128) through the HIP
     sampler (``idf_mis_merge`` mode 1, the reference's index order) against the CPU oracle run live on the same seeds."""

@@ -82,7 +82,7 @@ const char* idf_build_info(void);
  *   kernel takes a launch whose tile grid fills at least this share of the workgroup slots of its last round.  Initial value:
  *   env IDF_BIG_MIN_EFF or the library default.
  * (ABI 2 also exposed the kernel variants that were measured slower -- GEMM geometries 1..6, attention modes 1..14; they
- * left the library in ABI 3 and live under tools/ubench/archive/ with their measurements in profiles/r02_*.)
+ * left the library in ABI 3 and live under profiles/archive_rejected_kernels/ with their measurements in profiles/r02_*.)
  *   IDF_TUNE_ATTN8 (round 5, ABI 5): the d = 80 / d = 160 self and gated self-attention (n0 % 8 == n1 % 8 == 0, no mask) on the
  *   LDS-DMA kernel of attention8.hip (32 queries per wave, K / V^T rings, deferred-rescale running max, XCD-aware 1-D grid):
  *   0 = off (the register-staged 32-query kernel), 1 = on (d = 80: two 4-wave workgroups per CU; d = 160: one 8-wave workgroup

@@ -450,7 +450,9 @@ int launch_one(const AttnParams& p, int B, int order, hipStream_t s) {
   constexpr int LDS = ((MODE == 1 ? 2 : 3) * KVT * KCH * 8 + 2 * NMT * 32 * KVT) * 2;
   auto kern = attn8_kernel<DT, D, NW, MODE>;
   static std::atomic<unsigned long long> attr_done{0};
-  if (idf_lds_optin(reinterpret_cast<const void*>(kern), LDS, attr_done) != 0) return IDF_E_UNSUPPORTED;
+  //  an opt-in failure is reported as the HIP error it is, like the other launchers -- IDF_E_UNSUPPORTED hid it and, not
+  // being IDF_ATTN2_UNSUPPORTED, did not even fall back to the register-staged kernel
+  if (const int rc = idf_lds_optin(reinterpret_cast<const void*>(kern), LDS, attr_done)) return rc;
   const int nqb = (p.nq + NW * 32 - 1) / (NW * 32);
   hipLaunchKernelGGL(kern, dim3(nqb * p.H * B), dim3(NW * 64), LDS, s, p, nqb, order);
   return idf_launch_status();

@@ -29,7 +29,7 @@ struct AttnParams {
 // r03_shape_profile_B64_attn{1,2}.log); 3 = mode 1 with the plain block order (A/B of the XCD mapping); 4 / 5 = attention4w.hip
 // (round 6: the asm-scheduled stream, d = 40 only) with 128 queries per wave on one wave per SIMD / 64 on two (default 5).
 // The round-1 / round-2 variants this kernel replaced (attention2.hip: classic / lazy / software-pipelined online softmax;
-// attention5.hip: 8-wave ping-pong form) were measured slower and live under tools/ubench/archive/ with their logs in
+// attention5.hip: 8-wave ping-pong form) were measured slower and live under profiles/archive_rejected_kernels/ with their logs in
 // profiles/r02_attn_*.
 #define IDF_ATTN2_UNSUPPORTED (-100)
 #ifndef IDF_ATTN2_DEFAULT

@@ -27,7 +27,7 @@
 // (tools/ubench/mfma_power.hip), pure MFMA 1.75-1.88 at 1.65-1.79 GHz (mfma_sustain.hip).
 // Round 3: (a) the geometries that were measured slower (two 4-wave workgroups per CU, the role-split ping-pong kernel, the
 // four-stage 32-deep ring, the end / spread fill schedules) left the library -- source snapshot
-// tools/ubench/archive/gemm_big_r02.hip, numbers profiles/r02_pp_*, r02_shape_profile_B64_fill_*; (b) fused q | k | v
+// profiles/archive_rejected_kernels/gemm_big_r02.hip, numbers profiles/r02_pp_*, r02_shape_profile_B64_fill_*; (b) fused q | k | v
 // projection (VT): the output tiles whose columns lie at or beyond `vt_col0` run the SAME K loop with the MFMA operands
 // swapped, so a lane ends up with 16 consecutive TOKENS of one channel and stores V transposed (V^T[channel][token], the
 // layout the P.V MFMA's A operand wants) -- one launch reads the activation tile once for q, k and V^T instead of a second
@@ -364,6 +364,7 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] += bs[j >> 2][j & 3];
         }
+        [[maybe_unused]] float rbv[16];             // GST: the row bias of the wave's sample is part of the statistics' pivot
         if (epi & IDF_EPI_ROWBIAS) {
           const unsigned short* rb = p.rowbias + (size_t)(mc / p.rows_per_batch) * p.ld_rowbias + n;
           float r[16];
@@ -371,6 +372,10 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
           unpack8<DT>(*reinterpret_cast<const u32x4*>(rb + 8), r + 8);
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] += r[j];
+          if constexpr (GST) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rbv[j] = r[j];
+          }
         }
         if (epi & IDF_EPI_SILU) {
 #pragma unroll
@@ -427,7 +432,11 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
             unpack8<DT>(q1, r + 8);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-              const float d = (epi & IDF_EPI_BIAS) ? r[j] - bs[j >> 2][j & 3] : r[j];
+              // pivot of the shifted sums: conv bias + the sample's row bias (the time embedding of a ResBlock's first conv) --
+              // the per-column constants that move a channel's mean away from 0 (with the bias alone a 64-row chunk
+              // whose mean is ~100 standard deviations lost 2^-22 (mean / std)^2 of its M2 to cancellation)
+              float d = (epi & IDF_EPI_BIAS) ? r[j] - bs[j >> 2][j & 3] : r[j];
+              if (epi & IDF_EPI_ROWBIAS) d -= rbv[j];
               if (b == 0) { gt[j] = d; gt[16 + j] = d * d; }
               else { gt[j] += d; gt[16 + j] = fmaf(d, d, gt[16 + j]); }
             }
@@ -468,7 +477,9 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
         for (int j = 0; j < cpg; ++j) {
           const int col = g * cpg + j;
           const float s1 = csl[col], s2 = csl[WNC + col];
-          const float pc = (epi & IDF_EPI_BIAS) ? p.bias[nw + col] : 0.0f;
+          float pc = (epi & IDF_EPI_BIAS) ? p.bias[nw + col] : 0.0f;
+          if (epi & IDF_EPI_ROWBIAS)              // (the 64 rows of a wave tile belong to one sample: HW % 64 == 0, dispatcher)
+            pc += Elem<DT>::to_f32(p.rowbias[(size_t)(mw / p.rows_per_batch) * p.ld_rowbias + nw + col]);
           const float dm = s1 * inv_rows;
           ms += pc + dm;
           q += fmaxf(s2 - s1 * dm, 0.0f);
@@ -477,7 +488,9 @@ __device__ __forceinline__ void big_epilogue(const CoreParams& p, f32x16 (&acc)[
         float dev = 0.f;
         for (int j = 0; j < cpg; ++j) {
           const int col = g * cpg + j;
-          const float pc = (epi & IDF_EPI_BIAS) ? p.bias[nw + col] : 0.0f;
+          float pc = (epi & IDF_EPI_BIAS) ? p.bias[nw + col] : 0.0f;
+          if (epi & IDF_EPI_ROWBIAS)              // (the 64 rows of a wave tile belong to one sample: HW % 64 == 0, dispatcher)
+            pc += Elem<DT>::to_f32(p.rowbias[(size_t)(mw / p.rows_per_batch) * p.ld_rowbias + nw + col]);
           const float dd = pc + csl[col] * inv_rows - mean;
           dev = fmaf(dd, dd, dev);
         }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void mlp_dma16(const void* sbase /* wave-uniform */, 
 //     (first product | GELU + own k-step | partner's k-step): 14 % SLOWER (r04_mlp_phase_shift_*.log,
 //     r04_mlp_three_interval_rejected.log; both bit-exact).  Two accumulator chains in the first product: spills, -12 %.
 //     Round 5: the overlap INSIDE each wave, across chunks (first product of chunk g + 1 under the activation of chunk g, two
-//     pre-activation accumulators, no spills, bit-identical): 5-6 % SLOWER (tools/ubench/archive/mlp_pipelined_r05.hip,
+//     pre-activation accumulators, no spills, bit-identical): 5-6 % SLOWER (profiles/archive_rejected_kernels/mlp_pipelined_r05.hip,
 //     profiles/r05_mlp_pipelined_rejected.log) -- with two waves per SIMD the activation's VALU issue competes with both waves' MFMAs.
 //     Lock step is what this pipe likes: both waves of a SIMD in the same MFMA phase interleave perfectly, and a barrier
 //     costs least when everybody arrives together.

@@ -169,6 +169,9 @@ class UNetEngine:
         # (M32768 N3840 K1280, y read once) replaces the q | k GEMM + the batched 62-%-padded V^T GEMM (2.05 ms per 128-row forward
         # at 523 TF): 165.9 -> 164.7 ms per forward on one box, 64 no further gain (profiles/r05_vt_min_n_ab.log)
         self.vt_min_n = int(os.environ.get("IDF_VT_MIN_N", "256"))
+        if self.vt_min_n < 64 or self.vt_min_n % 64:
+            raise ValueError(f"IDF_VT_MIN_N={self.vt_min_n}: a positive multiple of 64 (tokens per sample from which the fused "
+                             "q | k | v launch is used; default 256)")
         self.use_graphs = use_graphs and self.device.type == "cuda"
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
@@ -796,24 +799,35 @@ class UNetEngine:
                      paired: bool = False) -> torch.Tensor:
         """eps = UNet(x, t | cond).  The launch sequence is captured once per (batch, resolution, fuser on/off, paired)
         into a hipGraph over static buffers and replayed; conditioning is copied into a static slot when it changes.
-        ``paired``: the caller guarantees x[B/2:] == x[:B/2] and t[B/2:] == t[:B/2] (a [cond | uncond] guidance batch)."""
-        B, Cx, H, W = x.shape
-        assert cond.B == B
+        ``paired``: a [cond | uncond] guidance batch -- rows [B/2, B) carry the latent and timestep of rows [0, B/2), and the
+        conditioning-free prefix of the network runs once (PAIR_HOIST).  Pass the B/2 DISTINCT rows (x: [B/2, ...], t: [B/2]): the
+        engine writes both halves of its static input itself, so the invariant holds by construction.  A full
+        [B, ...] batch is still accepted; it is then VERIFIED the first time a launch configuration is used (one compare + host
+        sync per (B, H, W, fuser, paired) key; on every call with IDF_DEBUG_PAIRED=1), not on later calls."""
+        B = cond.B
+        half = bool(paired) and x.shape[0] * 2 == B
+        if not half:
+            assert x.shape[0] == B
+        _, Cx, H, W = x.shape
         fuser_on = self.fuser_scale != 0.0
         key = (B, H, W, fuser_on, bool(paired))
-        if paired and (DEBUG_PAIRED or key not in self._paired_checked):
-            # the hoist computes the conditioning-free prefix for rows [0, B/2) only: a batch that is not a guidance pair would
-            # get silently wrong eps (and a captured graph would keep replaying the hoisted sequence).  Checked when a launch
-            # configuration is first used (one compare + host sync per key), on every call with IDF_DEBUG_PAIRED=1.
+        if paired and not half and (DEBUG_PAIRED or key not in self._paired_checked):
             n = B // 2
             if B % 2 or not (torch.equal(x[:n], x[n:]) and torch.equal(t[:n], t[n:])):
                 raise ValueError("forward_cond(paired=True): rows [B/2, B) must repeat the latent and timestep of rows [0, B/2)")
             self._paired_checked.add(key)
-        x_s = self.buf("io.x", x.shape, torch.float32)
+        x_s = self.buf("io.x", (B,) + tuple(x.shape[1:]), torch.float32)
         t_s = self.buf("io.t", (B,), torch.float32)
         eps_s = self.buf("io.eps", (B, self.n_out, H, W), torch.float32)
-        x_s.copy_(x)
-        t_s.copy_(t)
+        if half:
+            n = B // 2
+            x_s[:n].copy_(x)
+            x_s[n:].copy_(x)
+            t_s[:n].copy_(t)
+            t_s[n:].copy_(t)
+        else:
+            x_s.copy_(x)
+            t_s.copy_(t)
         if not self.use_graphs:
             self._forward_ops(x_s, t_s, cond, eps_s, fuser_on, paired)
         else:

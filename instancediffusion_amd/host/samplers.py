@@ -91,9 +91,10 @@ class _PLMSBase(object):
         """Guided eps for n trajectories: one batched forward of [cond | uncond] (plms.py:121-127)."""
         eng = self.engine
         if guided:
-            xx = torch.cat([x, x], 0)
-            t = torch.full((2 * n,), float(step), device=x.device, dtype=torch.float32)
-            e2 = eng.forward_cond(xx, t, cond_pair, out=eng.buf("smp.eps2", xx.shape, torch.float32), paired=True)
+            # the n distinct rows only: the engine writes both halves of its static [cond | uncond] input itself (ADVICE r5: the
+            # paired invariant is structural, not a promise checked once per launch configuration)
+            t = torch.full((n,), float(step), device=x.device, dtype=torch.float32)
+            e2 = eng.forward_cond(x, t, cond_pair, out=eng.buf("smp.eps2", (2 * n,) + tuple(x.shape[1:]), torch.float32), paired=True)
             return eng.ops.cfg_combine(e2[:n], e2[n:], guidance_scale, eng.ops.empty(x.shape, torch.float32))
         t = torch.full((n,), float(step), device=x.device, dtype=torch.float32)
         return eng.forward_cond(x, t, cond_pair)

@@ -294,6 +294,11 @@ def test_paired_flag_on_a_batch_that_is_not_a_guidance_pair_is_rejected(monkeypa
             eng.forward_cond(x2, torch.cat([t, t]), pair, paired=True)
         # without the flag the same batch is an ordinary 4-row forward
         assert torch.isfinite(eng.forward_cond(x2, torch.cat([t, t]), pair)).all()
+        # the structural form -- the caller hands over the n DISTINCT rows and the engine writes both halves of its
+        # input itself; nothing to verify, and the result is the full pair's, bit for bit (this is what the samplers do)
+        monkeypatch.setattr(engine_mod, "DEBUG_PAIRED", False)
+        half = eng.forward_cond(x, t, pair, paired=True)
+        assert tuple(half.shape) == (4, 4, 16, 16) and torch.equal(half, ok)
 
 
 def test_groupnorm_partials_travel_from_the_producing_conv_to_the_next_groupnorm(monkeypatch):

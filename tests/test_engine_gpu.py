@@ -225,16 +225,22 @@ def _forward_at_bench_width(tag, dtype, rows=64, min_big=150, min_att=10):
         slot = eng.gather_cond(bank, torch.tensor([0] * n + [1] * n, device="cuda"))
         x = inp["x"].cuda().float().repeat(2 * n, 1, 1, 1)
         t = inp["t"].cuda().float().repeat(2 * n)
-        big0, att0 = _stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), _stat(_lib.IDF_STAT_ATTN2_LAUNCHES)
+        big0, att0, gne0 = _stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), _stat(_lib.IDF_STAT_ATTN2_LAUNCHES), _stat(_lib.IDF_STAT_GN_EPI_LAUNCHES)
         eng.use_graphs = False
         eps = eng.forward_cond(x, t, slot)
-        big1, att1 = _stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), _stat(_lib.IDF_STAT_ATTN2_LAUNCHES)
+        big1, att1, gne1 = _stat(_lib.IDF_STAT_GEMM_BIG_LAUNCHES), _stat(_lib.IDF_STAT_ATTN2_LAUNCHES), _stat(_lib.IDF_STAT_GN_EPI_LAUNCHES)
         eng.use_graphs = True
         eps_g = eng.forward_cond(x, t, slot)                     # warm-up + capture + replay
         eps_g2 = eng.forward_cond(x, t, slot)
     n_st = eng.n_st
     print(f"[dispatch] {tag} {dtype} {rows}-row forward: {big1 - big0} persistent big-tile GEMM/conv launches, "
           f"{att1 - att0} LDS-DMA 64-query attention launches ({n_st} transformer layers)")
+    print(f"[dispatch] {tag} {dtype} {rows}-row forward: {gne1 - gne0} convs left their GroupNorm partials from the epilogue")
+    if min_big >= 150 and meta["latent"] == 64:
+        # at the bench widths the partials the engine asks for must come from the conv epilogue (32 of the 61 GroupNorms
+        # of a 64^2 forward: the 8^2 level's split-K convs and the decoder's concat inputs keep their own statistics pass) -- a
+        # dispatch change that silently sent them to the fallback pass (finer chunks than plain GroupNorm uses) would show here
+        assert gne1 - gne0 >= 30, "GroupNorm partials no longer come from the conv epilogue at the bench width"
     assert big1 - big0 >= min_big, "the benched GEMM / conv kernel did not serve this forward"
     assert att1 - att0 >= min_att, "the benched d = 40 attention kernel did not serve this forward"
     assert torch.equal(eps, eps_g) and torch.equal(eps_g, eps_g2), "hipGraph replay must equal the eager launch sequence"

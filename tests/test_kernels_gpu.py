@@ -1261,6 +1261,8 @@ def test_attention_v4_reference_value_paths(ref, attn4, case):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,extra,epi_path", [
     (8, 64, 320, 320, 1, "rowbias", True),        # ResBlock conv1 at 64^2: 128 tiles, 16 groups per wave column half
+    (8, 64, 320, 320, 1, "rowbias_big", True),    # a time-embedding row bias ~100 x the conv output's std (the pivot of
+                                                  # the epilogue's shifted sums must include it, or M2 cancels)
     (32, 32, 640, 640, 1, "res", True),           # conv2 + skip at 32^2: two n-tiles of 8 groups per wave column half
     (64, 16, 1280, 1280, 1, "rowbias", True),     # 16^2: one 256-row tile per sample, four n-tiles of 8 groups
     (64, 64, 320, 320, 2, None, True),            # Downsample (stride 2): 32^2 outputs
@@ -1285,6 +1287,8 @@ def test_conv3x3_gn_partial(ref, dt, B, H, Cin, Cout, stride, extra, epi_path):
     kw = {}
     if extra == "rowbias":
         kw["rowbias"] = dev(gen((B, Cout), 123).to(dt))
+    if extra == "rowbias_big":
+        kw["rowbias"] = dev((gen((B, Cout), 123) * 50.0).to(dt))
     if extra == "res":
         kw["res"] = dev(gen((B, Ho, Ho, Cout), 124).to(dt))
     shape = ops.gn_partial_shape(B, Ho * Ho, Cout)

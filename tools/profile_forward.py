@@ -16,6 +16,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 cfg = dict(SD15_BOX_CFG)
 model, sd = bench.build_model(cfg)
+if os.environ.get("PROFILE_DTYPE") == "fp16":          # (round 6: per-kernel fp16-vs-bf16 comparison, tools/dtype_kernel_diff.py)
+    model.compute_dtype = torch.float16
 dev = torch.device("cuda", 0)
 inputs, uc, gi, _ = bench.make_inputs(cfg, batch, dev)
 model.grounding_tokenizer_input = gi

@@ -342,7 +342,7 @@ def main():
         real_forward = eng.forward_cond
 
         def counting_forward(x, t, cond, out=None, **kw):
-            rows[eng.fuser_scale != 0.0] += int(x.shape[0])
+            rows[eng.fuser_scale != 0.0] += int(cond.B)               # (a paired forward is handed its n distinct rows; it runs cond.B = 2n)
             return real_forward(x, t, cond, out=out, **kw)
         eng.forward_cond = counting_forward
 

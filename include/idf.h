@@ -72,7 +72,9 @@ const char* idf_build_info(void);
  *   accumulators / Q / V^T fragments in asm-owned AGPRs, no per-tile overflow guard (one finiteness check per block, exact
  *   rerun otherwise) -- with 128 queries per wave and one wave per SIMD (4) or 64 queries per wave and two 4-wave workgroups
  *   per CU (5; the default: +6..8 % over mode 1 in isolation, -1.2 % on a 128-row forward).  Results of modes 1, 4, 5 are
- *   bit-identical unless a re-base / rerun path is taken.  Initial value: env IDF_ATTN2 or the default (5).
+ *   bit-identical unless a re-base / rerun path is taken.  6 = mode 4 as a persistent workgroup that prefetches the next query
+ *   block: measured 1-2 % slower, only in experiment builds of attention4w.hip (else served as mode 1).
+ *   Initial value: env IDF_ATTN2 or the default (5).
  *   IDF_TUNE_GEMM_RING (round 4): the launches the persistent kernel declines (small batches: every GEMM / conv of a 2-row
  *   forward) go to the LATENCY kernel -- the 128 x {128,64} tiles of the default small-tile kernels with a 4-5-stage LDS-DMA
  *   ring that has its K-tiles in flight from the first instruction instead of one at a time -- when their tile grid has at most

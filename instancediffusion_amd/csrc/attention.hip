@@ -437,7 +437,7 @@ int idf_attn2_mode() {
     // the same range idf_set_tuning accepts
     const char* e = getenv("IDF_ATTN2");
     const int v = e ? atoi(e) : IDF_ATTN2_DEFAULT;
-    g_attn2_mode = (v < 0 || v > 5) ? IDF_ATTN2_DEFAULT : v;
+    g_attn2_mode = (v < 0 || v > 6) ? IDF_ATTN2_DEFAULT : v;
   }
   return g_attn2_mode;
 }
@@ -472,7 +472,7 @@ extern "C" int idf_attention(const idf_attn_args* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (!a->qbits && idf_attn2_mode() >= 4) {
-    const int rc = idf_launch_attn4w(p, a->B, a->dtype, idf_attn2_mode() == 4 ? 4 : 2, s);
+    const int rc = idf_launch_attn4w(p, a->B, a->dtype, idf_attn2_mode(), s);
     if (rc != IDF_ATTN2_UNSUPPORTED) { ++idf_stat_attn2_launches; return rc; }
   }
   if (!a->qbits && idf_attn2_mode() > 0) {

@@ -41,7 +41,7 @@ int idf_attn2_mode();
 int idf_attn2_set_mode(int v);
 int idf_launch_attn4(const idfattn::AttnParams& p, int B, int dtype, hipStream_t s);
 // one-wave-per-SIMD form of the d = 40 kernel (attention4w.hip, round 6): 128 queries per wave, asm-scheduled stream
-int idf_launch_attn4w(const idfattn::AttnParams& p, int B, int dtype, int ng /* 4: one wave per SIMD, 2: two */, hipStream_t s);
+int idf_launch_attn4w(const idfattn::AttnParams& p, int B, int dtype, int variant /* mode 4: 128 queries per wave, 5: 64, 6: 128 + persistent */, hipStream_t s);
 // 32-queries-per-wave LDS-DMA kernel for d in {80, 160} (attention8.hip, round 5): K / V^T rings by LDS-DMA, deferred-rescale
 // running max, XCD-aware 1-D grid.  Mode (idf_set_tuning(IDF_TUNE_ATTN8), env IDF_ATTN8): 0 = off (attention.hip's register-staged
 // kernel); 1 = on (d = 80: two 4-wave workgroups per CU with the K fragments read one tile ahead; d = 160: one 8-wave workgroup

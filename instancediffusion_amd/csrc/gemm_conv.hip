@@ -942,7 +942,7 @@ extern "C" int idf_set_tuning(int knob, int value) {
     return idf_big_min_eff_pct(value);
   }
   if (knob == IDF_TUNE_ATTN2) {
-    if (value < 0 || value > 5) return IDF_E_ARG;
+    if (value < 0 || value > 6) return IDF_E_ARG;
     return idf_attn2_set_mode(value);
   }
   if (knob == IDF_TUNE_ATTN8) {

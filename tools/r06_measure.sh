@@ -43,7 +43,7 @@ if [ "$PART" = dtype ]; then
   for dt in bf16 fp16 bf16 fp16; do PROFILE_DTYPE=$dt timeout 300 python tools/profile_forward.py 128 20 graph 2>&1 | grep "graph replay" | sed "s/^/$dt /" | tee -a $O/dtype_graph_replay.log; done
 fi
 if [ "$PART" = configs ]; then
-  timeout 600 python tools/run_configs.py c2 c4 c5p c5s > $O/configs.log 2>&1; cp gpurun_out/configs.json $O/configs.json; grep -h img_per_s $O/configs.log | cut -c1-200
+  timeout 600 python tools/run_configs.py c2 c2x8 c4 c5p c5s > $O/configs.log 2>&1; cp gpurun_out/configs.json $O/configs.json; grep -h img_per_s $O/configs.log | cut -c1-200
   for b in 2 4 8 16 18 36 64 72 128; do timeout 300 python tools/profile_forward.py $b 20 graph 2>&1 | grep "graph replay" | tee -a $O/graph_replay_times.log; done
   IDF_BENCH_SINGLE_DEVICE=1 IDF_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --images-per-gpu 8 --no-alt-dtype > $O/bench_2rank_gloo.log 2>&1; tail -1 $O/bench_2rank_gloo.log | cut -c1-400
 fi

@@ -25,6 +25,8 @@ BASE = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolut
             test_drop_boxes=False, test_drop_points=False, test_drop_scribbles=True, test_drop_masks=True)
 CASES = {
     "c2": dict(drops={}, latent=64, n=4, boxes="c1", batch=1, mis=0.0, dtype=torch.bfloat16),
+    # the same at the reference CLI's own batch (inference.py --num_images 8): 16-row forwards instead of 2-row ones
+    "c2x8": dict(drops={}, latent=64, n=4, boxes="c1", batch=8, mis=0.0, dtype=torch.bfloat16),
     "c4": dict(drops=dict(test_drop_masks=False), latent=96, n=12, batch=1, mis=0.36, dtype=torch.bfloat16, segs=True, poly=True),
     "c5p": dict(drops=dict(test_drop_boxes=True), latent=64, n=8, batch=4, mis=0.36, dtype=torch.float16),
     "c5s": dict(drops=dict(test_drop_scribbles=False, test_drop_masks=False), latent=64, n=8, batch=4, mis=0.36,

@@ -184,13 +184,16 @@ int main(int argc, char** argv) {
         float er[3]; hipMemcpy(er, err, 12, hipMemcpyDeviceToHost);
         printf("%-11s d=%-3d keys %4d+%-3d lib %zu knob %d mode %d: rc %d %8.1f us %7.1f TF  csum %016llx  maxerr %.2e relrms %.2e\n", sh.name, sh.d,
                sh.n0, sh.n1, li, knob, m, rc, best * 1e3, flops / (best * 1e-3) / 1e12, cs, er[0], sqrt(er[1] / (er[2] + 1e-30)));
-        if (libs[li].trace4w_read && sh.d == 40 && sh.n0 > 77 && m == 4) {
-          unsigned long long tr[4][4];
+        if (libs[li].trace4w_read && sh.d == 40 && sh.n0 > 77 && m >= 4) {
+          unsigned long long tr[4][8];
           if (libs[li].trace4w_read(&tr[0][0]) == 0)
             for (int w = 0; w < 4; ++w) {
               const double nt = (double)tr[w][3];
               if (nt > 0) printf("    wave %d, per tile of the stream (%.0f tiles; 1792 cycles of MFMA each): block0 %.0f block1 %.0f wait+barrier %.0f = %.0f\n", w, nt,
                                  tr[w][0] / nt, tr[w][1] / nt, tr[w][2] / nt, (tr[w][0] + tr[w][1] + tr[w][2]) / nt);
+              const double nb = (double)tr[w][7];
+              if (nb > 0) printf("            per block (%.0f blocks): prologue + first tile + fill %.0f, stream %.0f, epilogue (+ launch gap when not persistent) %.0f\n", nb,
+                                 tr[w][4] / nb, tr[w][5] / nb, tr[w][6] / nb);
             }
         }
         if (libs[li].trace_read && sh.d == 40 && sh.n0 > 77 && m >= 1 && m != 4) {

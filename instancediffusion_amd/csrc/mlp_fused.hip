@@ -28,6 +28,9 @@
 // Roofline: MFMA-bound, 2 * M * (2560 * 320 + 320 * 1280) flops; HBM: 2 B in + 2 B out per element of x (+ residual read).
 #include "gemm_core.h"
 #include <cstdlib>
+#include <atomic>
+#include <type_traits>
+#include <utility>
 
 using namespace idfcore;
 
@@ -344,7 +347,414 @@ int launch_mlp320(const MlpParams& p, hipStream_t s) {
   return idf_launch_status();
 }
 
+
+// ====================================================================================================================
+// mlp320w_kernel -- the same feed-forward as ONE INSTRUCTION STREAM PER SIMD (round 6).
+//
+// mlp320_kernel's cycle trace (profiles/r04_mlp_trace_*.log): 4300-4450 cycles per chunk for 1920 cycles of matrix pipe -- both
+// waves of a SIMD run fold + GELU together with the pipe idle (~900), and ~1500 go to the chunk barrier, the exchange barrier
+// between the two waves of a row group, the LDS-DMA issue and the wait for pieces that were enqueued late.  Overlapping the
+// VALU work ACROSS the two waves (round 4) or inside each wave with compiler scheduling (round 5) lost 5-14 %: the 256-register
+// budget of two waves per SIMD forced the fold constants into just-in-time scalar LDS reads, which put LDS latency and a
+// 14-instruction dependent chain between two MFMAs of an in-order wave.  Here:
+//   * a workgroup is FOUR waves, one per SIMD, 512 registers each; wave w owns rows 32 w .. + 31 of the 128-row tile and ALL
+//     320 output columns -- no exchange of activated fragments, no second barrier, ONE barrier per chunk;
+//   * the x rows (80 registers, MFMA B operands) and the 10 output accumulators (160) live in AGPRs NAMED in the asm text
+//     (attention4w.hip's technique: the register allocator knows them only as clobbers);
+//   * software pipeline over chunks, one iteration j = { second product of chunk j - 1 (20 MFMAs) | first product of chunk j + 1
+//     (40 MFMAs, both 32 x 32 fragments, two independent chains) | fold + GEGLU of chunk j (144 VALU instructions, packed-fp32
+//     where the operation exists) }: the VALU statements are STAGE-ORDERED over the four register pairs of a fragment (a
+//     dependent instruction is >= 4 issue slots behind its producer) and spread ~3 per MFMA gap; LDS fragment / constant reads sit
+//     3 gaps ahead of their consumers with counted lgkmcnt waits; the iteration's 15-16 LDS-DMA pieces ride in the first gaps
+//     behind the barrier (W1 two chunks ahead, W2 / constants one -- the ring is the 8-wave kernel's: same LDS image, same
+//     packed operands);
+//   * the stream is generated (tools/gen_mlpw_stream.py -> mlpw_stream.inc): every statement is `asm volatile`, source order =
+//     issue order.
+// Same operations on the same operands in the same order per output element as mlp320_kernel: BIT-IDENTICAL results (the
+// harness' whole-output checksums).  The residual comes out of the x fragments in the AGPRs (two v_permlane32_swap per dword
+// turn the B-operand layout into the output layout): x is read from HBM once.
+// ====================================================================================================================
+constexpr int MW_XA = 0, MW_OA = 80, MW_NAGPR = 240;
+constexpr int MW_B2_OFF = 2 * SLOT_BYTES, MW_STG_OFF = MW_B2_OFF + MLP_C * 4, MW_SMEM = MW_STG_OFF + 4 * 2 * 2048;
+
+struct MwCtx {
+  unsigned w1a[4], w2a[2], cda;                 // LDS byte addresses of this iteration's fragment / constant reads (per lane)
+  f32x2 nmu2, rstd2, k1, k2, k3, one2;
+  float lo8, hi8;
+  const char* w1src; const char* w2src; const char* cdsrc;      // wave-uniform sources of this iteration's LDS-DMA pieces
+  unsigned w1_ustride, w2_tstride;              // bytes: 32 rows of W1, 64 rows of W2
+  unsigned w1_voff, w2_voff, cd_voff;           // per-lane source byte offsets
+  unsigned w1dst, w2dst, cddst;                 // LDS byte addresses of this wave's first piece
+  int wave;
+#ifdef IDF_MLPW_TRACE
+  mutable unsigned long long tr[12];            // cycle sums: [0..5] segments of mw_body_11, [6] its calls, [7] tile load, [8] epilogue, [9] pro + 01 + 10 + drain
+#endif
+};
+
+// Optional cycle trace (tools/build_mlpw_variant.sh <name> MW_TRACE=1 -- -DIDF_MLPW_TRACE; read through idf_mlpw_trace_read by
+// tools/ubench/mlp_harness.hip; the shipped library has none of it).  The marks are s_memtime into separate SGPR pairs, read
+// only at the end of the body: a wait for one of them inside the stream would also wait for the stream's LDS reads.
+#ifdef IDF_MLPW_TRACE
+__device__ unsigned long long idf_mlpw_trace_buf[4][12];
+#define MW_TR_DECL unsigned long long trm[7];
+#define MW_TR_MARK(i) asm volatile("s_memtime %0" : "=s"(trm[i]));
+#define MW_TR_END { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(trm[0]), "+s"(trm[1]), "+s"(trm[2]), "+s"(trm[3]), "+s"(trm[4]), "+s"(trm[5]), "+s"(trm[6])); \
+    for (int i = 0; i < 6; ++i) c.tr[i] += trm[i + 1] - trm[i]; c.tr[6] += 1; }
+#else
+#define MW_TR_DECL
+#define MW_TR_MARK(i)
+#define MW_TR_END
+#endif
+
+template <int R> __device__ __forceinline__ void mw_agpr_write(unsigned v) { asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(v), "n"(R)); }
+template <int R> __device__ __forceinline__ unsigned mw_agpr_read() {
+  unsigned v;
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "n"(R));
+  return v;
+}
+template <class F, int... I>
+__device__ __forceinline__ void mw_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void mw_static_for(F&& f) { mw_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// first product: acc (VGPRs; the activation reads them) (+)= W1 fragment (A, VGPRs) . x fragment KS (B, asm-owned AGPRs)
+template <int DT, int KS, bool FIRST> __device__ __forceinline__ void mw_mf1(f32x16& acc, const u32x4& w) {
+  constexpr int lo = MW_XA + 4 * KS;
+  if constexpr (FIRST) {
+    if constexpr (DT == IDF_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
+  } else {
+    if constexpr (DT == IDF_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
+  }
+}
+// second product: output accumulator A (asm-owned AGPRs) += W2 fragment (A, VGPRs) . activated fragment (B, VGPRs)
+template <int DT, int A> __device__ __forceinline__ void mw_mf2(const u32x4& w, const u32x4& h) {
+  constexpr int lo = MW_OA + 16 * A;
+  if constexpr (DT == IDF_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(h), "n"(lo), "n"(lo + 15));
+  else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(h), "n"(lo), "n"(lo + 15));
+}
+template <int OFF> __device__ __forceinline__ u32x4 mw_lds128(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF> __device__ __forceinline__ f32x4 mw_lds128f(unsigned addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int N> __device__ __forceinline__ void mw_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%c0)" ::"n"(N)); }
+// Two scalar fp32 instructions per pair, NOT v_pk_*_f32: in the shadow of an MFMA a packed-fp32 instruction costs the wave ~12
+// cycles, a scalar one ~5 (profiles/NOTES_r06.md: 144 packed instructions per chunk 3860 cycles per iteration, 232 scalar ones
+// 3230); -DMW_PACKED_VALU builds the packed form for A/B runs.
+#ifdef MW_PACKED_VALU
+__device__ __forceinline__ f32x2 mw_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 mw_pk_mul(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 mw_pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+#else
+__device__ __forceinline__ f32x2 mw_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  float x, y;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(a.x), "v"(b.x), "v"(c.x));
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a.y), "v"(b.y), "v"(c.y));
+  return f32x2{x, y};
+}
+__device__ __forceinline__ f32x2 mw_pk_mul(f32x2 a, f32x2 b) {
+  float x, y;
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
+  return f32x2{x, y};
+}
+__device__ __forceinline__ f32x2 mw_pk_add(f32x2 a, f32x2 b) {
+  float x, y;
+  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
+  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
+  return f32x2{x, y};
+}
+#endif
+__device__ __forceinline__ float mw_med3(float x, float lo /* uniform */, float hi) {
+  float d;
+  asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(lo), "v"(hi));
+  return d;
+}
+__device__ __forceinline__ float mw_exp2(float x) {
+  float d;
+  asm volatile("v_exp_f32_e32 %0, %1" : "=v"(d) : "v"(x));
+  return d;
+}
+__device__ __forceinline__ float mw_rcp(float x) {
+  float d;
+  asm volatile("v_rcp_f32_e32 %0, %1" : "=v"(d) : "v"(x));
+  return d;
+}
+template <int DT> __device__ __forceinline__ unsigned mw_cvt_pk(float lo, float hi) {
+  unsigned r;
+  if constexpr (DT == IDF_BF16) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+template <int H> __device__ __forceinline__ f32x2 mw_half(const f32x4& v) { return __builtin_shufflevector(v, v, 2 * H, 2 * H + 1); }
+template <int I> __device__ __forceinline__ f32x2 mw_pair(const f32x16& v) { return __builtin_shufflevector(v, v, I, I + 1); }
+// x fragment KS of the lane's row <- 16 bytes of global memory, straight into the AGPRs
+template <int KS> __device__ __forceinline__ void mw_load_x(const unsigned short* rowp) {
+  asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(rowp), "n"(MW_XA + 4 * KS), "n"(MW_XA + 4 * KS + 3), "n"(32 * KS) : "memory");
+}
+
+#define MW_TOP asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifndef MLPW_STREAM_INC
+#define MLPW_STREAM_INC "mlpw_stream.inc"
+#endif
+#include MLPW_STREAM_INC
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, const int tiles) {
+  asm volatile("" ::: "a0", "a239");               // the asm-owned AGPR block: this is where the kernel descriptor learns its size
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int G = gridDim.x;
+  const unsigned smem_lds = lds_u32(smem);
+
+  MwCtx c;
+  c.wave = wave;
+  c.k1 = f32x2{1.0142652e-3f, 1.0142652e-3f}; c.k2 = f32x2{-1.0677574e-1f, -1.0677574e-1f}; c.k3 = f32x2{-2.3011213f, -2.3011213f};
+  c.one2 = f32x2{1.0f, 1.0f};
+  c.lo8 = -8.0f; c.hi8 = 8.0f;
+  asm volatile("" : "+v"(c.k1), "+v"(c.k2), "+v"(c.k3), "+v"(c.one2), "+v"(c.hi8));
+  // LDS-DMA roles.  W1: piece (kt, u) = rows 8 (wave + 4 u) .. + 7 of K-tile kt (lane -> row + lane / 8, 16-B slot lane % 8; the
+  // swizzle (row >> 1) & 7 does not depend on u); W2: piece t = rows 16 (wave + 4 t) .. + 15 (lane -> row + lane / 4, slot lane % 4)
+  {
+    const int row = 8 * wave + (lane >> 3);
+    c.w1_voff = (unsigned)(row * p.ldw1 + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+    const int row2 = 16 * wave + (lane >> 2);
+    c.w2_voff = (unsigned)(row2 * p.ldw2 + (((lane & 3) ^ ((row2 >> 2) & 3)) << 3)) * 2u;
+    c.cd_voff = (unsigned)((lane & 31) * 16);
+    c.w1_ustride = (unsigned)(32 * p.ldw1 * 2);
+    c.w2_tstride = (unsigned)(64 * p.ldw2 * 2);
+  }
+  // fragment addressing (the 8-wave kernel's LDS image): W1 row 32 f + l31 of a K-tile, 16-B slot (2 (ks & 3) + hi) ^ sw1;
+  // W2 row 32 a + l31, slot (2 kk + hi) ^ sw2
+  const int sw1 = (l31 >> 1) & 7, sw2 = (l31 >> 2) & 3;
+  unsigned w1o[4], w2o[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w1o[i] = smem_lds + (unsigned)(l31 * 128 + (((2 * i + hi) ^ sw1) << 4));
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) w2o[kk] = smem_lds + (unsigned)(W1_BYTES + l31 * 64 + (((2 * kk + hi) ^ sw2) << 4));
+  const unsigned cdo = smem_lds + (unsigned)(W1_BYTES + W2_BYTES + 16 * hi);
+  const char* const w1g = reinterpret_cast<const char*>(p.w1);
+  const char* const w2g = reinterpret_cast<const char*>(p.w2p);
+  const char* const cdg = reinterpret_cast<const char*>(p.cd);
+  const unsigned w1_chunk = (unsigned)(64 * p.ldw1 * 2);         // bytes of 64 packed W1 rows
+
+  // iteration j of a tile: reads W1(j + 1) [slot (j + 1) & 1], the constants of chunk j [slot j & 1] and W2(j - 1) [slot (j + 1) & 1];
+  // its LDS-DMA pieces bring W1(j + 2) [slot j & 1], the constants of chunk j + 1 [slot (j + 1) & 1] and W2(j) [slot j & 1]
+  auto set_iter = [&](int j) {
+    const unsigned sj = (unsigned)((j & 1) * SLOT_BYTES), sn = (unsigned)(((j + 1) & 1) * SLOT_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.w1a[i] = w1o[i] + sn;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) c.w2a[kk] = w2o[kk] + sn;
+    c.cda = cdo + sj;
+    const int j2 = j + 2 >= MLP_NCH ? j + 2 - MLP_NCH : j + 2, j1 = j + 1 >= MLP_NCH ? j + 1 - MLP_NCH : j + 1;
+    c.w1src = w1g + (size_t)j2 * w1_chunk;
+    c.w2src = w2g + (size_t)j * 64;
+    c.cdsrc = cdg + (size_t)j1 * 512;
+    c.w1dst = smem_lds + sj + (unsigned)(wave * 1024);
+    c.w2dst = smem_lds + sj + (unsigned)(W1_BYTES + wave * 1024);
+    c.cddst = smem_lds + sn + (unsigned)(W1_BYTES + W2_BYTES);
+  };
+
+  int tile = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= tiles) return;
+  const float gate = p.gate ? p.gate[0] : 1.0f;
+
+  // kernel prologue: W1 of chunks 0 and 1 and the constants of chunk 0 (iteration 0 brings W2(0), W1(2), constants(1))
+  {
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          mlp_dma16(w1g + (size_t)ch * w1_chunk + u * c.w1_ustride + kt * 128, c.w1_voff,
+                    smem_lds + (unsigned)(ch * SLOT_BYTES + wave * 1024 + kt * 8192 + u * 4096));
+    if (wave == 3) mlp_dma16(cdg, c.cd_voff, smem_lds + (unsigned)(W1_BYTES + W2_BYTES));
+  }
+
+  f32x16 acc1[2][2];
+  u32x4 hh[2][2];
+  // b2 once into LDS: the epilogue reads it with LDS latency and without a vector-memory operation of the compiler's own
+  if (tid < MLP_C / 4) reinterpret_cast<f32x4*>(smem + MW_B2_OFF)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
+#ifdef IDF_MLPW_TRACE
+  for (int i = 0; i < 12; ++i) c.tr[i] = 0;
+  unsigned long long trt = __builtin_readcyclecounter();
+#define MW_TRT(i) { const unsigned long long now = __builtin_readcyclecounter(); c.tr[i] += now - trt; trt = now; }
+#else
+#define MW_TRT(i)
+#endif
+  // the first tile's rows; every later tile's arrive during the epilogue of the tile before (below)
+  auto row_ptr = [&](int t) { return p.x + (size_t)(t * MLP_BM + wave * 32 + l31) * p.ldx + 8 * hi; };
+  {
+    const unsigned short* xr = row_ptr(tile);
+    mw_static_for<20>([&](auto kc) { mw_load_x<decltype(kc)::value>(xr); });
+  }
+  f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)(tile * MLP_BM + wave * 32 + l31));
+  asm volatile("" : "+v"(st));                     // (arrived before the loop: see the pin inside the epilogue)
+  bool first = true;
+  for (;;) {
+    c.nmu2 = f32x2{-st[0], -st[0]};
+    c.rstd2 = f32x2{st[1], st[1]};
+    asm volatile("" : "+v"(c.nmu2), "+v"(c.rstd2));
+    mw_static_for<160>([&](auto rc) { mw_agpr_write<MW_OA + decltype(rc)::value>(0u); });
+    if (first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                              // the kernel prologue's pieces (and b2) are visible
+      first = false;
+    } else {
+      // the x loads went out inside the epilogue; only the two stores of its last fragment are younger (vector-memory
+      // operations retire in order): no wait for the store round trip
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    asm volatile("" ::: "memory");
+
+    MW_TRT(7)
+    set_iter(-1);
+    mw_pro<DT>(acc1[1], acc1[0], hh[1], hh[0], c);                 // first product of chunk 0 -> acc1[0]
+    set_iter(0);
+    mw_body_01<DT>(acc1[0], acc1[1], hh[1], hh[0], c);
+    MW_TRT(9)
+    for (int j = 1; j < MLP_NCH - 1; j += 2) {
+      set_iter(j);
+      mw_body_11<DT>(acc1[1], acc1[0], hh[0], hh[1], c);
+      set_iter(j + 1);
+      mw_body_11<DT>(acc1[0], acc1[1], hh[1], hh[0], c);
+    }
+    MW_TRT(10)
+    set_iter(MLP_NCH - 1);
+    mw_body_10<DT>(acc1[1], acc1[0], hh[0], hh[1], c);
+    set_iter(MLP_NCH);
+    mw_drain<DT>(acc1[0], acc1[1], hh[1], hh[0], c);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // the last MFMAs' results reach the AGPRs
+    MW_TRT(9)
+
+    // ---- tile epilogue: + b2, gate, + residual (out of the x fragments), 16-bit store: a lane holds 16 consecutive columns of
+    // its row (32 bytes).  As soon as a pair of x fragments has given its residual, the NEXT tile's rows are fetched into it.
+    const int next = tile + G;
+    const bool has_next = next < tiles;
+    const unsigned short* const xn = row_ptr(has_next ? next : tile);
+    if (has_next) st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)(next * MLP_BM + wave * 32 + l31));
+#ifdef MW_DIRECT_STORES
+    unsigned short* const orow = p.out + (size_t)(tile * MLP_BM + wave * 32 + l31) * p.ldo + 16 * hi;
+#else
+    // through the wave's own LDS slots (two, alternating; LDS operations of one wave execute in order: no wait between the
+    // write and the read) so that a store instruction covers 16 rows x 64 contiguous bytes
+    char* const stg = smem + MW_STG_OFF + wave * 4096;
+    const int sl_row = lane >> 2, sl_pc = lane & 3;
+    auto stg_f = [](int row) { return ((((row >> 2) ^ (row >> 3)) & 1) << 1) | (((row >> 1) ^ (row >> 3) ^ (row >> 4)) & 1); };
+    auto stg_at = [&](int slot, int row, int pc) { return reinterpret_cast<u32x4*>(stg + slot * 2048 + row * 64 + ((pc ^ stg_f(row)) << 4)); };
+    unsigned short* const orow = p.out + (size_t)(tile * MLP_BM + wave * 32 + sl_row) * p.ldo + sl_pc * 8;
+#endif
+    const char* const b2l = smem + MW_B2_OFF + 64 * hi;
+    mw_static_for<10>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      // (the next tile's statistics are pinned HERE, where 18 of this epilogue's stores are younger than their load: carried
+      // into the next iteration as a pending load, the compiler waits for them -- and for every store -- with vmcnt(0) at the loop head)
+      if constexpr (a == 9) asm volatile("" : "+v"(st));
+      float acc[16];
+      mw_static_for<16>([&](auto rc) { acc[decltype(rc)::value] = __uint_as_float(mw_agpr_read<MW_OA + 16 * a + decltype(rc)::value>()); });
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[e]), __float_as_uint(acc[8 + e]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[4 + e]), __float_as_uint(acc[12 + e]), false, false);
+        v[e] = __uint_as_float(s02[0]); v[4 + e] = __uint_as_float(s02[1]);
+        v[8 + e] = __uint_as_float(s13[0]); v[12 + e] = __uint_as_float(s13[1]);
+      }
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(b2l + (32 * a + 4 * jq) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * jq + e] += bq[e];
+      }
+      // residual columns 32 a + 16 hi .. + 15 of the lane's row: x fragments 2 a (hi = 0 lanes) / 2 a + 1 (hi = 1 lanes), whose
+      // second / first 8 elements sit in the other half-wave's registers
+      u32x4 r0, r1;
+      mw_static_for<4>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const unsigned xa = mw_agpr_read<MW_XA + 4 * (2 * a) + d>(), xb = mw_agpr_read<MW_XA + 4 * (2 * a + 1) + d>();
+        const auto sw = __builtin_amdgcn_permlane32_swap(xa, xb, false, false);
+        r0[d] = sw[0]; r1[d] = sw[1];
+      });
+      if (has_next) { mw_load_x<2 * a>(xn); mw_load_x<2 * a + 1>(xn); }
+      float r[16];
+      unpack8<DT>(r0, r);
+      unpack8<DT>(r1, r + 8);
+#pragma unroll
+      for (int jq = 0; jq < 16; ++jq) v[jq] = fmaf(gate, v[jq], r[jq]);
+#ifdef MW_DIRECT_STORES
+      *reinterpret_cast<u32x4*>(orow + 32 * a) = pack8<DT>(v);
+      *reinterpret_cast<u32x4*>(orow + 32 * a + 8) = pack8<DT>(v + 8);
+#else
+      *stg_at(a & 1, l31, 2 * hi) = pack8<DT>(v);
+      *stg_at(a & 1, l31, 2 * hi + 1) = pack8<DT>(v + 8);
+      asm volatile("" ::: "memory");
+      const u32x4 o0 = *stg_at(a & 1, sl_row, sl_pc), o1 = *stg_at(a & 1, sl_row + 16, sl_pc);
+      *reinterpret_cast<u32x4*>(orow + 32 * a) = o0;
+      *reinterpret_cast<u32x4*>(orow + (size_t)16 * p.ldo + 32 * a) = o1;
+#endif
+    });
+    MW_TRT(8)
+    if (!has_next) break;
+    tile = next;
+  }
+#ifdef IDF_MLPW_TRACE
+  if ((int)blockIdx.x == (int)gridDim.x / 2 && lane == 0) { for (int i = 0; i < 12; ++i) idf_mlpw_trace_buf[wave][i] = c.tr[i]; }
+#endif
+}
+
+template <int DT>
+int launch_mlp320w(const MlpParams& p, hipStream_t s) {
+  void (*kern)(const MlpParams, const int) = mlp320w_kernel<DT>;
+  static std::atomic<unsigned long long> attr_done{0};
+  if (const int e = idf_lds_optin(reinterpret_cast<const void*>(kern), MW_SMEM, attr_done)) return e;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int tiles = p.M / MLP_BM;
+  const int grid = tiles < cus ? tiles : cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), MW_SMEM, s, p, tiles);
+  return idf_launch_status();
+}
+
+// IDF_MLP_MODE: 0 = mlp320_kernel (two waves per SIMD), 1 = mlp320w_kernel (one instruction stream per SIMD)
+#ifndef IDF_MLP_MODE_DEFAULT
+#define IDF_MLP_MODE_DEFAULT 1
+#endif
+inline int mlp_mode() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("IDF_MLP_MODE"); v = e ? (e[0] == '0' ? 0 : 1) : IDF_MLP_MODE_DEFAULT; }
+  return v;
+}
+
 }  // namespace
+
+#ifdef IDF_MLPW_TRACE
+extern "C" int idf_mlpw_trace_read(unsigned long long* host /* [4][12] */) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(idf_mlpw_trace_buf), sizeof(idf_mlpw_trace_buf));
+}
+#endif
 
 #ifdef IDF_MLP_TRACE
 extern "C" int idf_mlp_trace_read(unsigned long long* host /* [4][10] */) {
@@ -371,5 +781,6 @@ extern "C" int idf_mlp_geglu(const idf_mlp_args* a, void* stream) {
   p.w2p = static_cast<const unsigned short*>(a->w2p); p.ldw2 = a->ldw2; p.b2 = a->b2; p.gate = a->gate;
   p.out = static_cast<unsigned short*>(a->out); p.ldo = a->ldo; p.M = a->M;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mlp_mode() == 1) return a->dtype == IDF_BF16 ? launch_mlp320w<IDF_BF16>(p, s) : launch_mlp320w<IDF_F16>(p, s);
   return a->dtype == IDF_BF16 ? launch_mlp320<IDF_BF16>(p, s) : launch_mlp320<IDF_F16>(p, s);
 }

@@ -163,6 +163,22 @@ int main(int argc, char** argv) {
       const double flop = 2.0 * Mt * ((double)N1 * C + (double)C * H);
       printf("    M %6d: fused %8.1f us (%6.1f TF)   two gemms %8.1f us (%6.1f TF)   %+5.1f %%\n", Mt, tf[1], flop / tf[1] * 1e-6, tg[1],
              flop / tg[1] * 1e-6, (tg[1] / tf[1] - 1.0) * 100.0);
+      // a -DIDF_MLPW_TRACE build (tools/build_mlpw_variant.sh <name> MW_TRACE=1 -- -DIDF_MLPW_TRACE): the stream kernel's trace
+      if (auto rdw = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "idf_mlpw_trace_read")) {
+        fused(Mt, dout); hipDeviceSynchronize();
+        unsigned long long tr[4][12];
+        if (rdw(&tr[0][0]) == 0 && Mt >= 262144) {
+          for (int w = 0; w < 4; ++w) {
+            const double nb = (double)tr[w][6];
+            if (nb == 0) continue;
+            const double nt = nb / 38.0;
+            double per = 0; for (int i = 0; i < 6; ++i) per += tr[w][i] / nb;
+            printf("      wgM wave%d per steady iteration: top %5.0f pre %5.0f dma-gaps %5.0f g2-rest %5.0f g1a %5.0f g1b+trail %5.0f = %5.0f cycles (1920 = pipe full)"
+                   " | per tile: steady %7.0f load %6.0f pro/01/10/drain %6.0f epilogue %6.0f\n", w, tr[w][0] / nb, tr[w][1] / nb, tr[w][2] / nb,
+                   tr[w][3] / nb, tr[w][4] / nb, tr[w][5] / nb, per, tr[w][10] / nt, tr[w][7] / nt, tr[w][9] / nt, tr[w][8] / nt);
+          }
+        }
+      }
       // a -DIDF_MLP_TRACE build of the library exports the cycle trace of the last fused launch
       if (auto rd = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "idf_mlp_trace_read")) {
         fused(Mt, dout); hipDeviceSynchronize();

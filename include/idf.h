@@ -90,8 +90,11 @@ const char* idf_build_info(void);
  *   0 = off (the register-staged 32-query kernel), 1 = on (d = 80: two 4-wave workgroups per CU; d = 160: one 8-wave workgroup
  *   per 256 queries, 4-wave workgroups below), 2 = 8-wave workgroups throughout, 3 = mode 1 with the plain block order,
  *   4 = d = 160 on 4-wave workgroups, 5 / 6 = d = 80 software-pipelined on 4- / 8-wave workgroups.
- *   Initial value: env IDF_ATTN8 or the default (1). */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4 };
+ *   Initial value: env IDF_ATTN8 or the default (1).
+ *   IDF_TUNE_MLP (round 6; a knob id, no new entry point): idf_mlp_geglu on 0 = mlp320_kernel (8 waves, two per SIMD),
+ *     1 = mlp320w_kernel (4 waves, one generated instruction stream per SIMD; default).  Same results bit for bit.  Env IDF_MLP_MODE.
+ */
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4, IDF_TUNE_MLP = 5 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2, IDF_STAT_ATTN8_LAUNCHES = 3,

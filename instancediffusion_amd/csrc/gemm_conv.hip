@@ -949,6 +949,10 @@ extern "C" int idf_set_tuning(int knob, int value) {
     if (value < 0 || value > 6) return IDF_E_ARG;
     return idf_attn8_set_mode(value);
   }
+  if (knob == IDF_TUNE_MLP) {
+    if (value < 0 || value > 1) return IDF_E_ARG;
+    return idf_mlp_set_mode(value);
+  }
   return IDF_E_ARG;
 }
 

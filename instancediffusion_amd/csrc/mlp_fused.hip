@@ -384,6 +384,8 @@ struct MwCtx {
   const char* w1src; const char* w2src; const char* cdsrc;      // wave-uniform sources of this iteration's LDS-DMA pieces
   unsigned w1_ustride, w2_tstride;              // bytes: 32 rows of W1, 64 rows of W2
   unsigned w1_voff, w2_voff, cd_voff;           // per-lane source byte offsets
+  const char* w1b[2]; const char* w2b[5]; const char* cdb;       // (MW_DMA_IMM) static sources: W1 rows 32 u .., W2 rows 64 t ..
+  unsigned w1_vj, w2_vj, cd_vj;                 // (MW_DMA_IMM) per-lane offsets of this iteration: + chunk offset
   unsigned w1dst, w2dst, cddst;                 // LDS byte addresses of this wave's first piece
   int wave;
 #ifdef IDF_MLPW_TRACE
@@ -512,6 +514,15 @@ template <int KS> __device__ __forceinline__ void mw_load_x(const unsigned short
   asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(rowp), "n"(MW_XA + 4 * KS), "n"(MW_XA + 4 * KS + 3), "n"(32 * KS) : "memory");
 }
 
+// one LDS-DMA piece as ONE statement: M0 = LDS base + LDSOFF straight from the add (no scalar temporaries), the global source =
+// sbase + voff + SRCOFF through the instruction's offset field -- which moves the LDS address as well (measured: with M0 =
+// base + LDSOFF the harness' fp64 check fails at 2.3e-1, with LDSOFF - SRCOFF the output is bit-identical; profiles/r06_mlpw_imm.log).
+// Same ~60 cycles per piece as the s_mov / s_add form, but no scalar temporaries: the kernel's 17 SGPR spills are gone.
+template <int LDSOFF, int SRCOFF> __device__ __forceinline__ void mw_dma(unsigned ldsbase /* uniform */, unsigned voff, const void* sbase /* uniform */) {
+  constexpr int L = LDSOFF - SRCOFF;
+  asm volatile("s_add_i32 m0, %0, %c1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%c4" ::"s"(ldsbase), "n"(L), "v"(voff), "s"(sbase), "n"(SRCOFF) : "memory");
+}
+
 #define MW_TOP asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #ifndef MLPW_STREAM_INC
 #define MLPW_STREAM_INC "mlpw_stream.inc"
@@ -558,6 +569,11 @@ __global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, cons
   const char* const w2g = reinterpret_cast<const char*>(p.w2p);
   const char* const cdg = reinterpret_cast<const char*>(p.cd);
   const unsigned w1_chunk = (unsigned)(64 * p.ldw1 * 2);         // bytes of 64 packed W1 rows
+#pragma unroll
+  for (int u = 0; u < 2; ++u) c.w1b[u] = w1g + (size_t)u * c.w1_ustride;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) c.w2b[t] = w2g + (size_t)t * c.w2_tstride;
+  c.cdb = cdg;
 
   // iteration j of a tile: reads W1(j + 1) [slot (j + 1) & 1], the constants of chunk j [slot j & 1] and W2(j - 1) [slot (j + 1) & 1];
   // its LDS-DMA pieces bring W1(j + 2) [slot j & 1], the constants of chunk j + 1 [slot (j + 1) & 1] and W2(j) [slot j & 1]
@@ -572,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, cons
     c.w1src = w1g + (size_t)j2 * w1_chunk;
     c.w2src = w2g + (size_t)j * 64;
     c.cdsrc = cdg + (size_t)j1 * 512;
+    c.w1_vj = c.w1_voff + (unsigned)j2 * w1_chunk; c.w2_vj = c.w2_voff + (unsigned)j * 64u; c.cd_vj = c.cd_voff + (unsigned)j1 * 512u;
     c.w1dst = smem_lds + sj + (unsigned)(wave * 1024);
     c.w2dst = smem_lds + sj + (unsigned)(W1_BYTES + wave * 1024);
     c.cddst = smem_lds + sn + (unsigned)(W1_BYTES + W2_BYTES);
@@ -742,13 +759,20 @@ int launch_mlp320w(const MlpParams& p, hipStream_t s) {
 #ifndef IDF_MLP_MODE_DEFAULT
 #define IDF_MLP_MODE_DEFAULT 1
 #endif
+int g_mlp_mode = -1;
 inline int mlp_mode() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("IDF_MLP_MODE"); v = e ? (e[0] == '0' ? 0 : 1) : IDF_MLP_MODE_DEFAULT; }
-  return v;
+  if (g_mlp_mode < 0) { const char* e = getenv("IDF_MLP_MODE"); g_mlp_mode = e ? (e[0] == '0' ? 0 : 1) : IDF_MLP_MODE_DEFAULT; }
+  return g_mlp_mode;
 }
 
 }  // namespace
+
+// idf_set_tuning(IDF_TUNE_MLP, v): returns the previous mode
+int idf_mlp_set_mode(int v) {
+  const int prev = mlp_mode();
+  g_mlp_mode = v;
+  return prev;
+}
 
 #ifdef IDF_MLPW_TRACE
 extern "C" int idf_mlpw_trace_read(unsigned long long* host /* [4][12] */) {

@@ -122,7 +122,7 @@ def test_argument_validation_without_gpu():
     assert lib.idf_groupnorm_apply(0x10000, 0x20008, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 0, None) == -2
     assert lib.idf_groupnorm_apply(0x10000, 0x20000, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 7, None) == -3
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
-    assert lib.idf_set_tuning(5, 0) == -1 and lib.idf_set_tuning(1, 7) == -1 and lib.idf_set_tuning(0, 4) == -1      # (round 6: attention modes 4 / 5 = attention4w.hip, 6 = its persistent form in experiment builds)
+    assert lib.idf_set_tuning(6, 0) == -1 and lib.idf_set_tuning(1, 7) == -1 and lib.idf_set_tuning(0, 4) == -1      # (round 6: attention modes 4 / 5 = attention4w.hip, 6 = its persistent form in experiment builds)
     # round 5 (ABI 5): the d = 80 / 160 LDS-DMA attention kernel's knob and launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 7) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 3)
@@ -130,6 +130,10 @@ def test_argument_validation_without_gpu():
     assert lib.idf_get_stat(_lib.IDF_STAT_ATTN8_LAUNCHES) == 0
     prev = lib.idf_set_tuning(1, 2)
     assert prev in (0, 1, 2, 3, 4, 5, 6) and lib.idf_set_tuning(1, prev) == 2
+    # round 6: which kernel serves idf_mlp_geglu (0 = 8 waves, 1 = one generated instruction stream per SIMD; default 1)
+    assert lib.idf_set_tuning(_lib.IDF_TUNE_MLP, 2) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_MLP, -1) == -1
+    prev = lib.idf_set_tuning(_lib.IDF_TUNE_MLP, 0)
+    assert prev == 1 and lib.idf_set_tuning(_lib.IDF_TUNE_MLP, prev) == 0
     # round 4: tile-count threshold of the latency kernel (0 = never), and its launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 77)
@@ -185,6 +189,24 @@ def test_attention4w_asm_owned_registers_are_left_alone_by_the_compiler():
     assert len(rep) == 4, sorted(rep)               # bf16 / fp16 x 128 / 64 queries per wave
     for name, r in rep.items():
         assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 50, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
+
+
+def test_mlp320w_stream_is_current_and_its_registers_are_left_alone():
+    """mlp_fused.hip's one-wave-per-SIMD kernel: (1) the checked-in instruction stream (csrc/mlpw_stream.inc) is what
+    tools/gen_mlpw_stream.py writes with its default options; (2) its asm-owned AGPR block (x fragments a0..a79, output
+    accumulators a80..a239) is not touched by compiler-generated code and the kernel has no scratch, in both element types."""
+    import importlib.util
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MW_")}
+    assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_mlpw_stream.py"), "--check"], env=env).returncode == 0
+    spec = importlib.util.spec_from_file_location("check_attn4w_isa", os.path.join(REPO, "tools", "check_attn4w_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.check(src=os.path.join(REPO, "instancediffusion_amd", "csrc", "mlp_fused.hip"), kernel="mlp320w_kernel")
+    assert len(rep) == 2, sorted(rep)
+    for name, r in rep.items():
+        assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 200, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
 
 
 def test_schema_matches_reference():

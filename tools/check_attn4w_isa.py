@@ -13,14 +13,15 @@ SRC = os.path.join(ROOT, "instancediffusion_amd", "csrc", "attention4w.hip")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form".split()
 
 
-def check(extra=()):
+def check(extra=(), src=SRC, kernel="attn4w_kernel"):
+    """src / kernel: the same scan for another file with asm-owned AGPRs (mlp_fused.hip's mlp320w_kernel)"""
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "a.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "--cuda-device-only", "-S", SRC, "-o", out], check=True,
-                       cwd=os.path.dirname(SRC))
+        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "--cuda-device-only", "-S", src, "-o", out], check=True,
+                       cwd=os.path.dirname(src))
         txt = open(out).read()
     report = {}
-    for name, body in re.findall(r"\n(_ZN\S*attn4w_kernel\S*):[^\n]*\n(.*?)\n\ts_endpgm", txt, flags=re.S):
+    for name, body in re.findall(r"\n(_ZN\S*" + kernel + r"\S*):[^\n]*\n(.*?)\n\ts_endpgm", txt, flags=re.S):
         in_asm, stray, scratch, mfma = False, [], 0, 0
         for line in body.split("\n"):
             t = line.strip()

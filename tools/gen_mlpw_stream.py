@@ -102,8 +102,19 @@ def const_reads(h, need):
     return rs
 
 
+DMA_IMM = os.environ.get("MW_DMA_IMM", "1") == "1"    # pieces as one asm statement with immediate offsets (mw_dma)
+
+
 def dma_pieces():
     ps = []
+    if DMA_IMM:
+        for kt in range(5):
+            for u in range(2):
+                ps.append(f"mw_dma<{kt * 8192 + u * 4096}, {kt * 128}>(c.w1dst, c.w1_vj, c.w1b[{u}]);")
+        for t in range(5):
+            ps.append(f"mw_dma<{t * 4096}, 0>(c.w2dst, c.w2_vj, c.w2b[{t}]);")
+        ps.append("if (c.wave == 3) mw_dma<0, 0>(c.cddst, c.cd_vj, c.cdb);")
+        return ps
     for kt in range(5):
         for u in range(2):
             ps.append(f"mlp_dma16(c.w1src + {u} * c.w1_ustride + {kt * 128}, c.w1_voff, c.w1dst + {kt * 8192 + u * 4096});")

@@ -2,7 +2,7 @@
 //
 // Same data layout as variant 2 (attention2.hip): 64 queries per wave in two groups of 32, swapped K.Q^T so a lane owns
 // a query column, K / V^T tiles staged by LDS-DMA, permuted K fragment rows so the packed P feeds P.V without lane
-// exchanges, softmax denominator from an all-ones V^T row.  What changed, and why (ISA notes in DESIGN.md on variant 2:
+// exchanges, softmax denominator from an all-ones V^T row.  What changed, and why (ISA notes in profiles/DESIGN_r01_r05_full.md on variant 2:
 // 253 VGPRs, 7 of 14 ds_read_b128 directly followed by s_waitcnt lgkmcnt(0), a 34-deep v_max3 chain and 18 v_mov per
 // tile, K/V re-fetched ~8x because the 16 query blocks of a (batch, head) were spread over the 8 XCD L2s):
 //

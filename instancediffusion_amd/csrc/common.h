@@ -84,7 +84,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 //   |gelu_erf_f(x) - x Phi(x)| <= 2.6e-5 for every x (fit on [-8, 8], tools/fit_gelu.py; outside, Phi is 0 / 1 to 1e-15 and
 //   the argument is clamped), i.e. ~1 % of the 2^-9 relative rounding of a 16-bit result of magnitude 1.
 // 9 VALU ops (2 transcendental) instead of the ~18 of an Abramowitz-Stegun erf: the GEGLU epilogue of the K = 320 layers
-// was 2.6x as long as their MFMA loop.  The coefficients carry the factor -log2(e) of exp -> exp2.
+// was 2.6x as long as their MFMA loop (profiles/DESIGN_r01_r05_full.md section 4).  The coefficients carry the factor -log2(e) of exp -> exp2.
 __device__ __forceinline__ float gelu_erf_f(float x) {
   const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
   const float x2 = xc * xc;

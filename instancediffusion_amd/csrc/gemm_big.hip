@@ -45,7 +45,7 @@ namespace {
 __device__ __attribute__((aligned(128))) unsigned short idf_zero_page[64];   // zero-initialised device memory
 
 // Wave tile: IDF_WAVE_ROWS rows x BN/2 columns.  64 (library): eight waves per workgroup, two per SIMD, 160 accumulator
-// registers per lane.  128 (experiment of tools/ubench/big_trace.hip, see DESIGN.md "What bounds the GEMM family"): four waves,
+// registers per lane.  128 (experiment of tools/ubench/big_trace.hip, see profiles/DESIGN_r01_r05_full.md "What bounds the GEMM family"): four waves,
 // one per SIMD with the whole 512-register budget -- 9 fragment reads per 20 MFMAs instead of 7 per 10.
 #ifndef IDF_WAVE_ROWS
 #define IDF_WAVE_ROWS 64

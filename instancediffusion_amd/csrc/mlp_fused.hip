@@ -641,9 +641,13 @@ __global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, cons
       __builtin_amdgcn_s_barrier();                              // the kernel prologue's pieces (and b2) are visible
       first = false;
     } else {
-      // the x loads went out inside the epilogue; only the two stores of its last fragment are younger (vector-memory
-      // operations retire in order): no wait for the store round trip
+      // the x loads went out inside the epilogue; only the stores of its last two fragments (4) are younger -- vector-memory
+      // operations retire in order: no wait for the store round trip
+#ifdef MW_DIRECT_STORES
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
     }
     asm volatile("" ::: "memory");
 
@@ -683,6 +687,7 @@ __global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, cons
     auto stg_f = [](int row) { return ((((row >> 2) ^ (row >> 3)) & 1) << 1) | (((row >> 1) ^ (row >> 3) ^ (row >> 4)) & 1); };
     auto stg_at = [&](int slot, int row, int pc) { return reinterpret_cast<u32x4*>(stg + slot * 2048 + row * 64 + ((pc ^ stg_f(row)) << 4)); };
     unsigned short* const orow = p.out + (size_t)(tile * MLP_BM + wave * 32 + sl_row) * p.ldo + sl_pc * 8;
+    u32x4 po0, po1;
 #endif
     const char* const b2l = smem + MW_B2_OFF + 64 * hi;
     mw_static_for<10>([&](auto ac) {
@@ -715,7 +720,9 @@ __global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, cons
         const auto sw = __builtin_amdgcn_permlane32_swap(xa, xb, false, false);
         r0[d] = sw[0]; r1[d] = sw[1];
       });
+#ifndef MW_NO_XLOAD              /* (timing experiment: wrong results) */
       if (has_next) { mw_load_x<2 * a>(xn); mw_load_x<2 * a + 1>(xn); }
+#endif
       float r[16];
       unpack8<DT>(r0, r);
       unpack8<DT>(r1, r + 8);
@@ -725,12 +732,20 @@ __global__ __launch_bounds__(256, 1) void mlp320w_kernel(const MlpParams p, cons
       *reinterpret_cast<u32x4*>(orow + 32 * a) = pack8<DT>(v);
       *reinterpret_cast<u32x4*>(orow + 32 * a + 8) = pack8<DT>(v + 8);
 #else
+      // (the read-back of fragment a is stored one fragment later, behind fragment a + 1's register traffic: the LDS round
+      // trip of every fragment was exposed otherwise)
+      if constexpr (a > 0) {
+        *reinterpret_cast<u32x4*>(orow + 32 * (a - 1)) = po0;
+        *reinterpret_cast<u32x4*>(orow + (size_t)16 * p.ldo + 32 * (a - 1)) = po1;
+      }
       *stg_at(a & 1, l31, 2 * hi) = pack8<DT>(v);
       *stg_at(a & 1, l31, 2 * hi + 1) = pack8<DT>(v + 8);
       asm volatile("" ::: "memory");
-      const u32x4 o0 = *stg_at(a & 1, sl_row, sl_pc), o1 = *stg_at(a & 1, sl_row + 16, sl_pc);
-      *reinterpret_cast<u32x4*>(orow + 32 * a) = o0;
-      *reinterpret_cast<u32x4*>(orow + (size_t)16 * p.ldo + 32 * a) = o1;
+      po0 = *stg_at(a & 1, sl_row, sl_pc); po1 = *stg_at(a & 1, sl_row + 16, sl_pc);
+      if constexpr (a == 9) {
+        *reinterpret_cast<u32x4*>(orow + 32 * a) = po0;
+        *reinterpret_cast<u32x4*>(orow + (size_t)16 * p.ldo + 32 * a) = po1;
+      }
 #endif
     });
     MW_TRT(8)

@@ -176,7 +176,7 @@ int main(int argc, char** argv) {
     }
     {   // GroupNorm of the same forward (two launches each: statistics, normalisation).  A one-pass form -- row chunk held in
         // registers, device-wide rendezvous per sample, one launch -- was built and measured here in round 4: correct, and 1.3x
-        // (2 rows) to 2.4-3x (128 rows) SLOWER (profiles/r04_gn_onepass_*.log, DESIGN.md "Measured and NOT shipped").
+        // (2 rows) to 2.4-3x (128 rows) SLOWER (profiles/r04_gn_onepass_*.log, profiles/DESIGN_r01_r05_full.md "Measured and NOT shipped").
       const int gn[][3] = {{4096, 320, 13}, {4096, 640, 2}, {4096, 960, 1}, {1024, 640, 11}, {1024, 1280, 1}, {1024, 1920, 1}, {1024, 320, 1},
                            {256, 1280, 11}, {256, 2560, 2}, {256, 640, 1}, {256, 1920, 1}, {64, 1280, 12}, {64, 2560, 3}};
       const size_t gws_bytes = (size_t)idf_groupnorm_ws_floats(R, 4096) * 4 + (1 << 20);

@@ -93,12 +93,17 @@ const char* idf_build_info(void);
  *   Initial value: env IDF_ATTN8 or the default (1).
  *   IDF_TUNE_MLP (round 6; a knob id, no new entry point): idf_mlp_geglu on 0 = mlp320_kernel (8 waves, two per SIMD),
  *     1 = mlp320w_kernel (4 waves, one generated instruction stream per SIMD; default).  Same results bit for bit.  Env IDF_MLP_MODE.
+ *   IDF_TUNE_QKV_ROW (round 6): the fused q | k | v projection of the C = 320 level (K = 320, N = 960, vt_col0 = 640, M % 128 == 0,
+ *     statistics handed in) on qkv320w_kernel (activation rows resident in registers): 0 = never, 1 = when the shape qualifies
+ *     (default).  Env IDF_QKV_ROW.
  */
-enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4, IDF_TUNE_MLP = 5 };
+enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4, IDF_TUNE_MLP = 5,
+       IDF_TUNE_QKV_ROW = 6 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2, IDF_STAT_ATTN8_LAUNCHES = 3,
-       IDF_STAT_GN_EPI_LAUNCHES = 4 /* idf_conv3x3 calls whose gn_partial came out of the conv epilogue, not the statistics pass */ };
+       IDF_STAT_GN_EPI_LAUNCHES = 4 /* idf_conv3x3 calls whose gn_partial came out of the conv epilogue, not the statistics pass */,
+       IDF_STAT_QKV_ROW_LAUNCHES = 6 /* fused q | k | v projections served by qkv320w_kernel (also counted in stat 0) */ };
 long long idf_get_stat(int stat);
 
 /* ---- GEMM: out[M,N] = epi( A[M,K] . W[N,K]^T ) ----------------------------------------------------------

@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // latency kernel above (round 4: 64-deep K-steps, one barrier per 16 MFMAs, one workgroup per CU) serves the opposite regime --
 // grids of <= 256 tiles, where a launch is a chain of dependent trips to memory -- and is chosen by tile count in launch().
 std::atomic<long long> idf_stat_gn_epi_launches{0};   // idf_conv3x3 calls whose GroupNorm partials came out of the epilogue (idf_get_stat)
-std::atomic<long long> idf_stat_ring_launches{0};     // launches of the latency kernel (idf_get_stat)
+std::atomic<long long> idf_stat_ring_launches{0};
+std::atomic<long long> idf_stat_qkvw_launches{0};     // fused q | k | v projections served by qkv320w_kernel (idf_get_stat)     // launches of the latency kernel (idf_get_stat)
 int g_big_mode = -2;
 inline int gemm_big_mode() {
   if (g_big_mode == -2) {
@@ -949,6 +950,10 @@ extern "C" int idf_set_tuning(int knob, int value) {
     if (value < 0 || value > 6) return IDF_E_ARG;
     return idf_attn8_set_mode(value);
   }
+  if (knob == IDF_TUNE_QKV_ROW) {
+    if (value < 0 || value > 1) return IDF_E_ARG;
+    return idf_qkvw_set_mode(value);
+  }
   if (knob == IDF_TUNE_MLP) {
     if (value < 0 || value > 1) return IDF_E_ARG;
     return idf_mlp_set_mode(value);
@@ -962,6 +967,7 @@ extern "C" long long idf_get_stat(int stat) {
   if (stat == IDF_STAT_GEMM_RING_LAUNCHES) return idf_stat_ring_launches.load();
   if (stat == IDF_STAT_ATTN8_LAUNCHES) return idf_stat_attn8_launches.load();
   if (stat == IDF_STAT_GN_EPI_LAUNCHES) return idf_stat_gn_epi_launches.load();
+  if (stat == IDF_STAT_QKV_ROW_LAUNCHES) return idf_stat_qkvw_launches.load();
   return -1;
 }
 
@@ -1023,6 +1029,10 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
     const bool self_ln = (a->epi & IDF_EPI_LN_ROW) && !a->ln_stats;
     if (self_ln && !a->ln_stats_out) return IDF_E_ARG;        // the fallback's second GEMM needs them somewhere
     p.vt_out = (unsigned short*)a->vt_out; p.ld_vt = a->ld_vt; p.vt_col0 = a->vt_col0;
+    {   // the row-resident kernel of the C = 320 level (qkv_fused.hip); counted with the persistent-kernel launches
+      const int r = idf_launch_qkv320w(p, a->dtype, s);
+      if (r != IDF_BIG_UNSUPPORTED) { if (r == 0) { ++idf_stat_big_launches; ++idf_stat_qkvw_launches; } return r; }
+    }
     if (gemm_big_mode() > 0) {
       const int r = idf_launch_big(p, a->dtype, false, gemm_big_mode() == 2, s, nullptr);
       if (r != IDF_BIG_UNSUPPORTED) return r;

@@ -27,12 +27,14 @@
 // summation order of the second GEMM.  LDS: 2 x 61 KB ring + 8 KB exchange + 16 KB epilogue staging = 146 KB.
 // Roofline: MFMA-bound, 2 * M * (2560 * 320 + 320 * 1280) flops; HBM: 2 B in + 2 B out per element of x (+ residual read).
 #include "gemm_core.h"
+#include "mw_prims.h"
 #include <cstdlib>
 #include <atomic>
 #include <type_traits>
 #include <utility>
 
 using namespace idfcore;
+using namespace idfmw;
 
 namespace {
 
@@ -55,7 +57,6 @@ struct MlpParams {
   int M;
 };
 
-__device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(size_t)p; }
 // LDS-DMA as inline assembly (see gemm_big.hip): lds = LDS byte address of lane 0's 16-B slot, through M0
 __device__ __forceinline__ void mlp_dma16(const void* sbase /* wave-uniform */, unsigned voff_bytes, unsigned lds) {
   lds = __builtin_amdgcn_readfirstlane(lds);
@@ -374,7 +375,7 @@ int launch_mlp320(const MlpParams& p, hipStream_t s) {
 // harness' whole-output checksums).  The residual comes out of the x fragments in the AGPRs (two v_permlane32_swap per dword
 // turn the B-operand layout into the output layout): x is read from HBM once.
 // ====================================================================================================================
-constexpr int MW_XA = 0, MW_OA = 80, MW_NAGPR = 240;
+constexpr int MW_NAGPR = 240;
 constexpr int MW_B2_OFF = 2 * SLOT_BYTES, MW_STG_OFF = MW_B2_OFF + MLP_C * 4, MW_SMEM = MW_STG_OFF + 4 * 2 * 2048;
 
 struct MwCtx {
@@ -407,121 +408,6 @@ __device__ unsigned long long idf_mlpw_trace_buf[4][12];
 #define MW_TR_MARK(i)
 #define MW_TR_END
 #endif
-
-template <int R> __device__ __forceinline__ void mw_agpr_write(unsigned v) { asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(v), "n"(R)); }
-template <int R> __device__ __forceinline__ unsigned mw_agpr_read() {
-  unsigned v;
-  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "n"(R));
-  return v;
-}
-template <class F, int... I>
-__device__ __forceinline__ void mw_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void mw_static_for(F&& f) { mw_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// first product: acc (VGPRs; the activation reads them) (+)= W1 fragment (A, VGPRs) . x fragment KS (B, asm-owned AGPRs)
-template <int DT, int KS, bool FIRST> __device__ __forceinline__ void mw_mf1(f32x16& acc, const u32x4& w) {
-  constexpr int lo = MW_XA + 4 * KS;
-  if constexpr (FIRST) {
-    if constexpr (DT == IDF_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
-  } else {
-    if constexpr (DT == IDF_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "n"(lo), "n"(lo + 3));
-  }
-}
-// second product: output accumulator A (asm-owned AGPRs) += W2 fragment (A, VGPRs) . activated fragment (B, VGPRs)
-template <int DT, int A> __device__ __forceinline__ void mw_mf2(const u32x4& w, const u32x4& h) {
-  constexpr int lo = MW_OA + 16 * A;
-  if constexpr (DT == IDF_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(h), "n"(lo), "n"(lo + 15));
-  else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(h), "n"(lo), "n"(lo + 15));
-}
-template <int OFF> __device__ __forceinline__ u32x4 mw_lds128(unsigned addr) {
-  u32x4 r;
-  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-template <int OFF> __device__ __forceinline__ f32x4 mw_lds128f(unsigned addr) {
-  f32x4 r;
-  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-template <int N> __device__ __forceinline__ void mw_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%c0)" ::"n"(N)); }
-// Two scalar fp32 instructions per pair, NOT v_pk_*_f32: in the shadow of an MFMA a packed-fp32 instruction costs the wave ~12
-// cycles, a scalar one ~5 (profiles/NOTES_r06.md: 144 packed instructions per chunk 3860 cycles per iteration, 232 scalar ones
-// 3230); -DMW_PACKED_VALU builds the packed form for A/B runs.
-#ifdef MW_PACKED_VALU
-__device__ __forceinline__ f32x2 mw_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-  f32x2 d;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-__device__ __forceinline__ f32x2 mw_pk_mul(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ f32x2 mw_pk_add(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-#else
-__device__ __forceinline__ f32x2 mw_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-  float x, y;
-  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(a.x), "v"(b.x), "v"(c.x));
-  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a.y), "v"(b.y), "v"(c.y));
-  return f32x2{x, y};
-}
-__device__ __forceinline__ f32x2 mw_pk_mul(f32x2 a, f32x2 b) {
-  float x, y;
-  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
-  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
-  return f32x2{x, y};
-}
-__device__ __forceinline__ f32x2 mw_pk_add(f32x2 a, f32x2 b) {
-  float x, y;
-  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
-  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
-  return f32x2{x, y};
-}
-#endif
-__device__ __forceinline__ float mw_med3(float x, float lo /* uniform */, float hi) {
-  float d;
-  asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(lo), "v"(hi));
-  return d;
-}
-__device__ __forceinline__ float mw_exp2(float x) {
-  float d;
-  asm volatile("v_exp_f32_e32 %0, %1" : "=v"(d) : "v"(x));
-  return d;
-}
-__device__ __forceinline__ float mw_rcp(float x) {
-  float d;
-  asm volatile("v_rcp_f32_e32 %0, %1" : "=v"(d) : "v"(x));
-  return d;
-}
-template <int DT> __device__ __forceinline__ unsigned mw_cvt_pk(float lo, float hi) {
-  unsigned r;
-  if constexpr (DT == IDF_BF16) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-template <int H> __device__ __forceinline__ f32x2 mw_half(const f32x4& v) { return __builtin_shufflevector(v, v, 2 * H, 2 * H + 1); }
-template <int I> __device__ __forceinline__ f32x2 mw_pair(const f32x16& v) { return __builtin_shufflevector(v, v, I, I + 1); }
-// x fragment KS of the lane's row <- 16 bytes of global memory, straight into the AGPRs
-template <int KS> __device__ __forceinline__ void mw_load_x(const unsigned short* rowp) {
-  asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(rowp), "n"(MW_XA + 4 * KS), "n"(MW_XA + 4 * KS + 3), "n"(32 * KS) : "memory");
-}
-
-// one LDS-DMA piece as ONE statement: M0 = LDS base + LDSOFF straight from the add (no scalar temporaries), the global source =
-// sbase + voff + SRCOFF through the instruction's offset field -- which moves the LDS address as well (measured: with M0 =
-// base + LDSOFF the harness' fp64 check fails at 2.3e-1, with LDSOFF - SRCOFF the output is bit-identical; profiles/r06_mlpw_imm.log).
-// Same ~60 cycles per piece as the s_mov / s_add form, but no scalar temporaries: the kernel's 17 SGPR spills are gone.
-template <int LDSOFF, int SRCOFF> __device__ __forceinline__ void mw_dma(unsigned ldsbase /* uniform */, unsigned voff, const void* sbase /* uniform */) {
-  constexpr int L = LDSOFF - SRCOFF;
-  asm volatile("s_add_i32 m0, %0, %c1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%c4" ::"s"(ldsbase), "n"(L), "v"(voff), "s"(sbase), "n"(SRCOFF) : "memory");
-}
 
 #define MW_TOP asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #ifndef MLPW_STREAM_INC

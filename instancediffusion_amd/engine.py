@@ -28,6 +28,11 @@ from .host.unet import Downsample, ResBlock, UNetModel, Upsample
 LN_SELF_MODE = int(os.environ.get("IDF_LN_SELF", "1"))
 if LN_SELF_MODE not in (0, 1, 2):          # any other value would leave LN_ROW consumers reading statistics nobody wrote
     raise ValueError(f"IDF_LN_SELF={LN_SELF_MODE}: must be 0, 1 or 2")
+# Round 6: the fused q | k | v projection of the C = 320 level runs on the row-resident kernel (csrc/qkv_fused.hip), which takes
+# the LayerNorm statistics from the caller: there the producers of the self-attention / gated self-attention input (proj_in,
+# attn1's out-projection: plain GEMMs, whose epilogue partials make the statistics almost free) emit them even in mode 1, while
+# the cross-attention query -- fed by the fused feed-forward kernel, which cannot emit them -- keeps summing its own.
+QKV_ROW = os.environ.get("IDF_QKV_ROW", "1") != "0"
 OBJ_TOKENS = 184
 MASK_RES = 64                  # the reference applies the fuser mask only when H*W == 64*64 (attention.py:195)
 
@@ -591,7 +596,7 @@ class UNetEngine:
             # through base + b*N, ld = B*N), replacing the second GEMM V^T = Wv . y^T (M = C: 62 % tile padding at C = 320)
             # that re-read y.  The LayerNorm statistics come from the K loop itself where that is free (C = 320), else `st`.
             vtg = self.buf("st.vtg", (C, B * N))
-            own = self._ln_self(C)
+            own = self._qkv_self(C, N)
             qk = ops.gemm(y, a["wqkv"], self.buf("st.qk", (B * N, 2 * C)), bias=a["dqkv"],
                           ln_row=(None if own else st, a["cqkv"]), ln_stats_out=st if own else None,
                           vt_out=vtg).view(B, N, 2 * C)
@@ -617,6 +622,10 @@ class UNetEngine:
             ops.attention(qk[:, :, :C], qk[:, :, C:], vt, N, att, self.heads, k1=kv_extra[0], vt1=kv_extra[1],
                           n1=OBJ_TOKENS, qbits=vis[0], kbits0=vis[1], kbits1=vis[2])
         return att
+
+    def _qkv_self(self, C, N):
+        """Does the fused q | k | v projection sum its own statistics?  Not where the row-resident kernel takes the launch."""
+        return self._ln_self(C) and not (QKV_ROW and C == 320 and self.vt_global and N % 64 == 0 and N >= self.vt_min_n)
 
     @staticmethod
     def _ln_self(C):
@@ -657,16 +666,22 @@ class UNetEngine:
         g = ops.groupnorm(x, self.buf("gn", x.shape), p["norm"][0], p["norm"][1], 1e-6, False, partial=gnp)
         st = self.buf("st.stats", (M, 2), torch.float32)
         own = self._ln_self(C)
-        pre, ffs = (None if own else st), (st if LN_SELF_MODE <= 1 else None)   # which producers emit statistics
-        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b, out_stats=pre)
+        own_qkv = self._qkv_self(C, N)
+        # which producers emit statistics: `pqkv` those in front of a q | k | v projection, `pre` the one in front of the
+        # cross-attention query, `ffs` those in front of a feed-forward
+        pre, ffs = (None if own else st), (st if LN_SELF_MODE <= 1 else None)
+        pqkv = None if own_qkv else st
+        y = ops.gemm(g.view(M, C), p["proj_in"].w, self.buf("st.x", (M, C)), bias=p["proj_in"].b, out_stats=pqkv)
         # --- self attention (attention.py:334): LN norm1
         att = self._self_attn(p["attn1"], y, st, B, N, C)
-        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y, out_stats=pre)
+        ops.gemm(att.view(M, C), p["attn1"]["out"].w, y, bias=p["attn1"]["out"].b, res=y,
+                 out_stats=pqkv if fuser_on else pre)
         if dup:
             x, y = self._dup(x, "st.x_in2"), self._dup(y.view(B, N, C), "st.x2").view(2 * M, C)
-            if pre is not None:
+            if (pqkv if fuser_on else pre) is not None:
                 st = self._dup(st.view(B, N, 2), "st.stats2").view(2 * M, 2)
-                pre = st
+                pre = st if pre is not None else None
+                pqkv = st if pqkv is not None else None
                 ffs = st if ffs is not None else None
             else:
                 st = self.buf("st.stats", (2 * M, 2), torch.float32)

@@ -127,6 +127,19 @@ int main(int argc, char** argv) {
         }
       std::sort(t[0].begin(), t[0].end()); std::sort(t[1].begin(), t[1].end());
       const double flop = 2.0 * Mt * N * C, bytes = (double)Mt * (C + N) * 2;
+      if (auto rd = (int (*)(unsigned long long*))dlsym(h, "idf_qkvw_trace_read")) {
+        unsigned long long tr[4][16];
+        tune(IDF_TUNE_QKV_ROW, 1); run(Mt, 1); hipDeviceSynchronize();
+        if (rd(&tr[0][0]) == 0)
+          for (int w = 0; w < 4; w += 3) {
+            const double nq = (double)tr[w][4], nv = (double)tr[w][10], nt = nq / 9.0;
+            if (nq == 0) continue;
+            printf("    wgM wave%d  qq step: top %5.0f pre+dma-gaps %5.0f gaps..23 %5.0f gaps 24..+trail %5.0f = %5.0f | vv step: top %5.0f dma %5.0f ..23 %5.0f rest %5.0f = %5.0f (1280 = pipe full)"
+                   " | per tile: head %6.0f pro %6.0f qq-steps %6.0f qv+vv+v_ %6.0f\n", w, tr[w][0] / nq, tr[w][1] / nq, tr[w][2] / nq, tr[w][3] / nq,
+                   (tr[w][0] + tr[w][1] + tr[w][2] + tr[w][3]) / nq, tr[w][6] / nv, tr[w][7] / nv, tr[w][8] / nv, tr[w][9] / nv,
+                   (tr[w][6] + tr[w][7] + tr[w][8] + tr[w][9]) / nv, tr[w][12] / nt, tr[w][13] / nt, tr[w][14] / nt, 0.0);
+          }
+      }
       printf("  M %6d: gemm_big %7.1f us (%6.1f TF, %4.2f TB/s)   qkv320w %7.1f us (%6.1f TF, %4.2f TB/s)   %+5.1f %%\n", Mt, t[0][1], flop / t[0][1] * 1e-6,
              bytes / t[0][1] * 1e-6, t[1][1], flop / t[1][1] * 1e-6, bytes / t[1][1] * 1e-6, (t[0][1] / t[1][1] - 1.0) * 100.0);
     }

@@ -135,6 +135,11 @@ template <int LDSOFF, int SRCOFF> __device__ __forceinline__ void mw_dma(unsigne
 }
 
 
+// fragment KA of the AGPR block <- 16 bytes at byte offset 32 KO of the lane's row pointer (KA != KO: a second row group)
+template <int KA, int KO> __device__ __forceinline__ void mw_load_x2(const unsigned short* rowp) {
+  asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(rowp), "n"(MW_XA + 4 * KA), "n"(MW_XA + 4 * KA + 3), "n"(32 * KO) : "memory");
+}
+
 // ---- additions of qkv_fused.hip
 // transposed first product: acc (+)= x fragment KS (A, asm-owned AGPRs) . W fragment (B, VGPRs): a lane then owns an output
 // COLUMN (W row) and its registers the 32 tokens of the wave

@@ -1125,6 +1125,72 @@ def test_gemm_fused_qkv_transposed_v(ops, M, C, own):
     assert torch.equal(qk2.cpu(), exact[:, :2 * C]) and torch.equal(vt2.cpu(), exact[:, 2 * C:].t())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [131072, 262144 + 256 * 7])
+def test_gemm_fused_qkv_row_kernel(M, dtype):
+    """qkv_fused.hip: the fused q | k | v projection of the C = 320 level on the row-resident kernel (idf_gemm with vt_out takes it
+    from two 256-row tiles per CU up when the statistics are handed in).  Against fp32 LayerNorm -> Linear, against the persistent
+    kernel on the same operands (the mean term of the fold rides the MFMAs as 16-bit hi + lo products: a fraction of the outputs may
+    differ by one ulp, no more), every copy of a row bitwise equal whatever tile / wave / row group computed it, launch counted; and
+    exact data with the identity fold ((mu, rstd) = (0, 1), c = d = 0) must equal the plain product bit for bit."""
+    import torch.nn.functional as F
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.ops import HipOps
+    ops = HipOps(dtype)
+    lib = _lib.load()
+    C = 320
+    gamma, beta = 1 + 0.2 * gen((C,), 401), 0.3 * gen((C,), 402)
+    rows = 4096
+    x = (gen((rows, C), 403) * 1.5 + 0.8 * gen((rows, 1), 404)).to(dtype)
+    x = x.repeat(M // rows + 1, 1)[:M].contiguous().cuda()
+    w = gen((3 * C, C), 405, C ** -0.5)
+    w16 = (w * gamma[None, :]).to(dtype)
+    c, d = w16.float().sum(1).cuda(), (w @ beta).cuda()
+    w16 = w16.cuda()
+    st = ops.empty((M, 2), torch.float32)
+    ops.row_stats(x, st, 1e-5)
+    want = F.layer_norm(x[:rows].float(), (C,), gamma.cuda(), beta.cuda(), 1e-5) @ w.cuda().t()
+    outs = {}
+    for mode in (1, 0):
+        prev = lib.idf_set_tuning(_lib.IDF_TUNE_QKV_ROW, mode)
+        qk, vt = ops.empty((M, 2 * C)), ops.empty((C, M))
+        n0 = lib.idf_get_stat(_lib.IDF_STAT_QKV_ROW_LAUNCHES)
+        ops.gemm(x, w16, qk, bias=d, ln_row=(st, c), vt_out=vt)
+        torch.cuda.synchronize()
+        served = lib.idf_get_stat(_lib.IDF_STAT_QKV_ROW_LAUNCHES) - n0
+        lib.idf_set_tuning(_lib.IDF_TUNE_QKV_ROW, prev)
+        assert served == mode
+        outs[mode] = (qk, vt)
+    qk, vt = outs[1]
+    tol = {torch.bfloat16: (BF16_TOL, BF16_TOL / 2), torch.float16: (2.0 ** -10, 2.0 ** -11)}[dtype]
+    e_qk, e_v = rel_rms(qk[:rows], want[:, :2 * C]), rel_rms(vt[:, :rows].t(), want[:, 2 * C:])
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    scale = float(want.abs().max())
+    dq = float((qk.float() - outs[0][0].float()).abs().max()) / scale
+    dv = float((vt.float() - outs[0][1].float()).abs().max()) / scale
+    nq = float((qk != outs[0][0]).float().mean())
+    print(f"[parity] q|k|v row kernel M{M} {dtype}: q|k rel-rms {e_qk:.3e}, V^T rel-rms {e_v:.3e}; vs persistent kernel max diff / max "
+          f"{dq:.2e} / {dv:.2e}, differing q|k elements {nq:.2e}")
+    assert relmax(qk[:rows], want[:, :2 * C]) < tol[0] and e_qk < tol[1]
+    assert relmax(vt[:, :rows].t(), want[:, 2 * C:]) < tol[0] and e_v < tol[1]
+    assert dq <= ulp and dv <= ulp and nq < 1e-2
+    assert torch.equal(qk[:rows], qk[rows:2 * rows]) and torch.equal(qk[:rows], qk[M - (M % rows or rows) - rows:][:rows])
+    assert torch.equal(vt[:, :rows], vt[:, rows:2 * rows])
+    # exact data
+    g = torch.Generator().manual_seed(406)
+    ai = torch.randint(-3, 4, (M, C), generator=g).to(dtype).cuda()
+    wi = torch.randint(-3, 4, (3 * C, C), generator=g).to(dtype).cuda()
+    st0 = torch.tensor([0.0, 1.0]).repeat(M, 1).cuda()
+    zero = torch.zeros(3 * C, device="cuda")
+    qk2, vt2 = ops.empty((M, 2 * C)), ops.empty((C, M))
+    n0 = lib.idf_get_stat(_lib.IDF_STAT_QKV_ROW_LAUNCHES)
+    ops.gemm(ai, wi, qk2, bias=zero, ln_row=(st0, zero), vt_out=vt2)
+    torch.cuda.synchronize()
+    assert lib.idf_get_stat(_lib.IDF_STAT_QKV_ROW_LAUNCHES) - n0 == 1
+    exact = (ai.float() @ wi.float().t()).to(dtype)
+    assert torch.equal(qk2, exact[:, :2 * C]) and torch.equal(vt2, exact[:, 2 * C:].t())
+
+
 def test_gemm_fused_qkv_f16_and_argument_checks():
     from instancediffusion_amd import _lib
     from instancediffusion_amd.ops import HipOps

@@ -2,12 +2,14 @@
 (qkv_fused.hip: the fused q | k | v projection of a C = 320 transformer block with the activation rows resident in registers).
 
 Same rules as tools/gen_mlpw_stream.py (every statement `asm volatile`, LDS reads LA gaps ahead of their consumers in FIFO order
-with counted lgkmcnt waits -- LDS WRITES count too, they retire in the same queue).  One pipeline step i of a 128-row tile:
-    top      s_waitcnt vmcnt(VMC) + s_barrier: the LDS-DMA pieces of step i - 1 (W chunk i + 1) landed; the VMC stores that step
-             issued behind them may still be in flight
-    MFMA     first product of chunk i + 1 (64 W rows: two 32 x 32 fragments, two independent chains, 40 MFMAs); the 10 LDS-DMA
-             pieces of chunk i + 2 ride in front of / in its first gaps
-    epilogue of chunk i: LayerNorm fold + bias, 16-bit, through the wave's LDS staging slot, 4 stores
+with counted lgkmcnt waits -- LDS WRITES count too, they retire in the same queue).  A wave owns TWO groups of 32 rows of a 256-row tile; a work item = (W chunk, row group), 30 per tile, chunk-major, so that a
+chunk stays in LDS for both row groups (half the LDS-DMA pieces and half the barriers per flop of a one-group tile).  One
+pipeline step s:
+    top      (steps whose MFMAs start a new chunk: RGM == 0) s_waitcnt vmcnt(VMC) + s_barrier: the chunk's LDS-DMA pieces landed;
+             the VMC stores issued behind them may still be in flight
+    MFMA     first product of item s + 1 = row group RGM of its chunk (64 W rows: two 32 x 32 fragments, two independent
+             chains, 40 MFMAs); five of the NEXT chunk's ten LDS-DMA pieces of the wave ride in front of / in its first gaps
+    epilogue of item s: LayerNorm fold + bias, 16-bit, through the wave's LDS staging slot, 4 stores
 Chunks 0..9 are q | k columns (a lane owns a token, stores token-major rows of 128 B), chunks 10..14 V columns, computed with the
 MFMA operands swapped (a lane owns a channel and 32 tokens: V^T rows of 64 B).  Variants: pro (MFMA of chunk 0 only), qq, qv, vv,
 v_ (epilogue of chunk 14 only; it also fetches the next tile's rows BEFORE its stores).
@@ -20,10 +22,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "instancediffusion_amd", "csrc", "qkvw_stream.inc")
 LA = int(os.environ.get("QW_LA", 3))
-PRE_DMA = int(os.environ.get("QW_PRE_DMA", 3))
+PRE_DMA = int(os.environ.get("QW_PRE_DMA", 2))
 MAXV = int(os.environ.get("QW_MAXV", 6))          # epilogue statements per MFMA gap at most; the rest trails
 NO_EPI = os.environ.get("QW_NO_EPI") == "1"       # timing experiments (wrong results)
 NO_DMA = os.environ.get("QW_NO_DMA") == "1"
+NO_STORE = os.environ.get("QW_NO_STORE", "")      # "q" / "v" / "qv": the q | k / V^T stores left out (timing experiments)
 
 
 class Stream:
@@ -54,33 +57,33 @@ class Stream:
 
 
 def mf_items(kind):
-    """[(statement, read name, read expr)] of the 40 MFMAs of a chunk"""
+    """[(statement, read name, read expr)] of the 40 MFMAs of an item; the x fragments of row group RGM are a[80 RGM + 4 ks ..]"""
     fn = "mw_mf1" if kind == "q" else "mw_mf1t"
     out = []
     for i in range(40):
         ks, f = i >> 1, i & 1
         name = f"w_{ks}_{f}"
         first = "true" if ks == 0 else "false"
-        out.append((f"{fn}<DT, {ks}, {first}>(accN[{f}], {name});", name,
+        out.append((f"{fn}<DT, 20 * RGM + {ks}, {first}>(accN[{f}], {name});", name,
                     f"const u32x4 {name} = mw_lds128<{(ks >> 2) * 8192 + f * 4096}>(c.w1a[{ks & 3}]);"))
+    # k-step 20: the LayerNorm mean term -mu c[n] as four 16-bit products (c and -mu split hi + lo; fragment 40 + RGM of the
+    # AGPR block holds the lane's token side, the c table in LDS the W-row side): acc leaves the MFMA as x . w - mu c
+    for f in range(2):
+        name = f"wx_{f}"
+        out.append((f"{fn}<DT, 40 + RGM, false>(accN[{f}], {name});", name, f"const u32x4 {name} = mw_lds128<{512 * f}>(c.cxa);"))
     return out
 
 
 def epi_q():
-    """epilogue of a q | k chunk: [(kind, code, needs, defines)]; kind 'r' hoistable constant read, 'l' in-place LDS operation,
-    's' plain statement"""
+    """epilogue of a q | k item: [(kind, code, needs, defines)]; kind 'r' hoistable constant read, 'l' in-place LDS operation,
+    's' plain statement.  acc = x . w - mu c (the mean term rode the MFMAs): v = rstd acc + d"""
     it = []
     for f in range(2):
         for q in range(4):
-            it.append(("r", f"const f32x4 cq{f}{q} = mw_lds128f<{(32 * f + 8 * q) * 4}>(c.cdq);", [], f"cq{f}{q}"))
+            it.append(("r", f"const f32x4 dq{f}{q} = mw_lds128f<{(32 * f + 8 * q) * 4}>(c.cdq);", [], f"dq{f}{q}"))
         for q in range(4):
             for e in range(4):
-                it.append(("s", f"const float t{f}{q}{e} = mw_fma(c.nmu, cq{f}{q}[{e}], accC[{f}][{4 * q + e}]);", [f"cq{f}{q}"], None))
-        for q in range(4):
-            it.append(("r", f"const f32x4 dq{f}{q} = mw_lds128f<{3840 + (32 * f + 8 * q) * 4}>(c.cdq);", [], f"dq{f}{q}"))
-        for q in range(4):
-            for e in range(4):
-                it.append(("s", f"const float v{f}{q}{e} = mw_fma(c.rstd, t{f}{q}{e}, dq{f}{q}[{e}]);", [f"dq{f}{q}"], None))
+                it.append(("s", f"const float v{f}{q}{e} = mw_fma(c.rstd, accC[{f}][{4 * q + e}], dq{f}{q}[{e}]);", [f"dq{f}{q}"], None))
         for q in range(4):
             for h in range(2):
                 it.append(("s", f"const unsigned p{f}{q}{h} = mw_cvt_pk<DT>(v{f}{q}{2 * h}, v{f}{q}{2 * h + 1});", [], None))
@@ -89,25 +92,23 @@ def epi_q():
     for i in range(4):
         it.append(("l", f"const u32x4 o{i} = mw_lds128<0>(c.qr[{i}]);", [], f"o{i}"))
     for i in range(4):
-        it.append(("s", f"mw_store128(c.qst[{i}], o{i}, c.obase);", [f"o{i}"], None))
+        if "q" not in NO_STORE:
+            it.append(("s", f"mw_store128(c.qst[{i}], o{i}, c.obase);", [f"o{i}"], None))
+        else:
+            it.append(("s", f"asm volatile(\"\" :: \"v\"(o{i}));", [f"o{i}"], None))
     return it
 
 
 def epi_v():
+    """epilogue of a V item (a lane owns channel n, its registers the tokens 8 q + 4 hi + e): v = rstd[token] acc + d[n]"""
     it = []
     for f in range(2):
-        it.append(("r", f"const float cn{f} = mw_lds32f<{128 * f}>(c.cdv);", [], f"cn{f}"))
-        it.append(("r", f"const float dn{f} = mw_lds32f<{3840 + 128 * f}>(c.cdv);", [], f"dn{f}"))
+        it.append(("r", f"const float dn{f} = mw_lds32f<{128 * f}>(c.cdv);", [], f"dn{f}"))
         for q in range(4):
-            for h in range(2):
-                it.append(("r", f"const f32x4 s{f}{q}{h} = mw_lds128f<{64 * q + 16 * h}>(c.stt);", [], f"s{f}{q}{h}"))
+            it.append(("r", f"const f32x4 s{f}{q} = mw_lds128f<{32 * q}>(c.stt);", [], f"s{f}{q}"))
         for q in range(4):
             for e in range(4):
-                it.append(("s", f"const float t{f}{q}{e} = mw_fma(s{f}{q}{e >> 1}[{2 * (e & 1)}], cn{f}, accC[{f}][{4 * q + e}]);",
-                           [f"s{f}{q}{e >> 1}", f"cn{f}"], None))
-        for q in range(4):
-            for e in range(4):
-                it.append(("s", f"const float v{f}{q}{e} = mw_fma(s{f}{q}{e >> 1}[{2 * (e & 1) + 1}], t{f}{q}{e}, dn{f});", [f"dn{f}"], None))
+                it.append(("s", f"const float v{f}{q}{e} = mw_fma(s{f}{q}[{e}], accC[{f}][{4 * q + e}], dn{f});", [f"s{f}{q}", f"dn{f}"], None))
         for q in range(4):
             for h in range(2):
                 it.append(("s", f"unsigned p{f}{q}{h} = mw_cvt_pk<DT>(v{f}{q}{2 * h}, v{f}{q}{2 * h + 1});", [], None))
@@ -124,20 +125,24 @@ def epi_v():
             it.append(("l", f"const u32x4 o{f}{i} = mw_lds128<{2048 * f}>(c.vr[{i}]);", [], f"o{f}{i}"))
     for f in range(2):
         for i in range(2):
-            it.append(("s", f"mw_store128(c.vst[{i}], o{f}{i}, c.vtb[{f}]);", [f"o{f}{i}"], None))
+            if "v" not in NO_STORE:
+                it.append(("s", f"mw_store128(c.vst[{i}], o{f}{i}, c.vtb[{f}]);", [f"o{f}{i}"], None))
+            else:
+                it.append(("s", f"asm volatile(\"\" :: \"v\"(o{f}{i}));", [f"o{f}{i}"], None))
     return it
 
 
 def dma_pieces():
-    return [f"mw_dma<{kt * 8192 + u * 4096}, {kt * 128}>(c.w1dst, c.w1_vj, c.w1b[{u}]);" for kt in range(5) for u in range(2)]
+    """the wave's pieces (kt, u = RGM) of the next chunk: rows 8 (wave + 4 u) .. + 7 of K-tile kt"""
+    return [f"mw_dma<{kt * 8192} + RGM * 4096, {kt * 128}>(c.w1dst, c.w1_vj, c.w1b[RGM]);" for kt in range(5)]
 
 
 def build(name, epi, mf, top=True, xload=False):
     st = Stream()
     args = "f32x16 (&accC)[2], f32x16 (&accN)[2], const QwCtx& c"
-    st.lines.append(f"template <int DT, int VMC> __device__ __forceinline__ void {name}({args}) {{")
+    st.lines.append(f"template <int DT, int VMC, int RGM> __device__ __forceinline__ void {name}({args}) {{")
     if top:
-        st.lines.append("  mw_wait_vm_barrier<VMC>();")
+        st.lines.append("  if constexpr (RGM == 0) mw_wait_vm_barrier<VMC>();")
     mfs = mf_items(mf) if mf else []
     ngap = len(mfs)
     pieces = dma_pieces() if (mf and not NO_DMA) else []
@@ -177,8 +182,9 @@ def build(name, epi, mf, top=True, xload=False):
             hp[0] += 1
 
     if xload:
-        st.lines.append("  if (c.has_next) { mw_static_for<20>([&](auto kc) { mw_load_x<decltype(kc)::value>(c.xnext); }); "
-                        "asm volatile(\"global_load_dwordx2 a[240:241], %0, off\" ::\"v\"(c.snext) : \"memory\"); }")
+        st.lines.append("  if (c.has_next) { mw_static_for<20>([&](auto kc) { mw_load_x2<decltype(kc)::value, decltype(kc)::value>(c.xnext); "
+                        "mw_load_x2<20 + decltype(kc)::value, decltype(kc)::value>(c.xnext2); }); "
+                        "asm volatile(\"global_load_dwordx2 a[168:169], %0, off\\n\\tglobal_load_dwordx2 a[170:171], %0, off offset:256\" ::\"v\"(c.snext) : \"memory\"); }")
     issue_upto(0)
     for s in pre:
         st.lines.append("  " + s)

@@ -40,7 +40,7 @@ constexpr int QW_BM = 256, QW_C = 320, QW_N = 960, QW_NCH = 15, QW_VCH0 = 10;   
 constexpr int QW_SLOT = 5 * 64 * 128;                                               // one W chunk: 5 K-tiles x [64 rows][64 k]
 constexpr int QW_CX_OFF = 2 * QW_SLOT, QW_CD_OFF = QW_CX_OFF + (QW_N + 33) * 16, QW_ST_OFF = QW_CD_OFF + QW_N * 4;
 constexpr int QW_STG_OFF = (QW_ST_OFF + 4 * 256 + 127) & ~127;                       // (the staging swizzle XORs address bits 4..6)
-constexpr int QW_SMEM = QW_STG_OFF + 4 * 4096;
+constexpr int QW_SMEM = QW_STG_OFF + 4 * 8192;
 constexpr int QW_NAGPR = 172;   // x fragments a0..a159 (row group r at 80 r), a160..167 the two groups' mean fragments, a168:171 the next tile's (mu, rstd)
 
 struct QwParams {
@@ -57,8 +57,8 @@ struct QwCtx {
   unsigned w1a[4];                       // LDS byte addresses of the W fragment reads of the chunk whose MFMAs run (per lane, by ks & 3)
   unsigned cdq, cdv, stt;                // d of the item in its epilogue (q | k: + 16 hi; V: + 4 l31); its row group's rstd table + 16 hi
   unsigned cxa;                          // the lane's row of the c table for the chunk whose MFMAs run (hi = 1 lanes: the zero row)
-  unsigned qw[8], qr[4], vw[2], vr[2];   // staging slot: q | k write (by 16-B slot) / read-back addresses, V^T write / read-back
-  unsigned qst[4], vst[2];               // per-lane store offsets (bytes)
+  unsigned qw[8], qr[4], vw[4];          // staging slot: q | k write (by 16-B slot) / read-back addresses (both images), V^T write (row group, half)
+  unsigned qst[4], vstw[4];              // per-lane store offsets (bytes)
   const void* obase; const void* vtb[2]; // uniform store bases of this step
   float rstd;                            // of the lane's token row in the row group whose item is in its epilogue
   unsigned w1dst, w1_vj; const char* w1b[2];
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(256, 1) void qkv320w_kernel(const QwParams p, const
   for (int i = 0; i < 4; ++i) w1o[i] = smem_lds + (unsigned)(l31 * 128 + (((2 * i + hi) ^ sw1) << 4));
   // staging slot of the wave (4 KB).  q | k image: [32 tokens][128 B], 16-B slot ^= (row >> 1) & 7; a lane writes 8 B of
   // slot s = 4 f + q of its token row (+ 8 hi inside the slot), reads back rows lane / 8 + 8 i, slot lane % 8.
-  // V^T image per fragment (2 KB): [32 channels][64 B], slot ^= (row >> 2) & 3; a lane writes slots 2 hi, 2 hi + 1 of its
-  // channel row, reads back rows lane / 4 + 16 i, slot lane % 4.
+  // V^T image per fragment (4 KB, the slot is 8 KB): [32 channels][128 B = the wave's 64 tokens], same swizzle; a lane of row
+  // group r writes slots 4 r + 2 hi, + 1 of its channel row; read back (by the chunk's second item) as the q | k image.
   {
-    const unsigned stg = smem_lds + (unsigned)(QW_STG_OFF + wave * 4096);
+    const unsigned stg = smem_lds + (unsigned)(QW_STG_OFF + wave * 8192);
     const unsigned base = stg + (unsigned)(l31 * 128 + 8 * hi + (sw1 << 4));
 #pragma unroll
     for (int s = 0; s < 8; ++s) c.qw[s] = base ^ (unsigned)(16 * s);
@@ -111,13 +111,11 @@ __global__ __launch_bounds__(256, 1) void qkv320w_kernel(const QwParams p, const
       c.qst[i] = (unsigned)(row * p.ldo * 2 + (lane & 7) * 16);
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) c.vw[s] = stg + (unsigned)(l31 * 64 + (((2 * hi + s) ^ ((l31 >> 2) & 3)) << 4));
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (lane >> 2) + 16 * i;
-      c.vr[i] = stg + (unsigned)(row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
-      c.vst[i] = (unsigned)(row * p.ld_vt * 2 + (lane & 3) * 16);
-    }
+      for (int s = 0; s < 2; ++s) c.vw[2 * r + s] = stg + (unsigned)(l31 * 128 + (((4 * r + 2 * hi + s) ^ sw1) << 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.vstw[i] = (unsigned)(((lane >> 3) + 8 * i) * p.ld_vt * 2 + (lane & 7) * 16);
   }
   const unsigned cd_lds = smem_lds + (unsigned)QW_CD_OFF;
 
@@ -181,9 +179,10 @@ __global__ __launch_bounds__(256, 1) void qkv320w_kernel(const QwParams p, const
     c.stt = smem_lds + (unsigned)(QW_ST_OFF + wave * 256 + rg * 128 + 16 * hi);
     const size_t m0 = (size_t)tile * QW_BM + wave * 64 + rg * 32;
     c.obase = reinterpret_cast<const char*>(p.out) + m0 * p.ldo * 2 + (size_t)ce * 128;
+    const size_t m0w = (size_t)tile * QW_BM + wave * 64;           // (V^T rows are stored for both row groups at once)
 #pragma unroll
     for (int f = 0; f < 2; ++f)
-      c.vtb[f] = reinterpret_cast<const char*>(p.vt) + ((size_t)(64 * (ce - QW_VCH0) + 32 * f) * p.ld_vt + m0) * 2;
+      c.vtb[f] = reinterpret_cast<const char*>(p.vt) + ((size_t)(64 * (ce - QW_VCH0) + 32 * f) * p.ld_vt + m0w) * 2;
   };
 
   for (;;) {
@@ -229,19 +228,19 @@ __global__ __launch_bounds__(256, 1) void qkv320w_kernel(const QwParams p, const
     set_step(QIT - 1);
     qw_qv<DT, 4, 0>(acc[1], acc[0], c);                            // epilogue of the last q | k item, MFMAs of the first V item
     set_step(QIT);
-    qw_vv<DT, 4, 1>(acc[0], acc[1], c);
+    qw_vv1<DT, 4, 1>(acc[0], acc[1], c);                           // (a V chunk's first item leaves its half of the V^T rows in LDS: no stores)
     for (int s = QIT + 1; s < NIT - 1; s += 2) {                   // steps 21 .. 28
       set_step(s);
-      qw_vv<DT, 4, 0>(acc[1], acc[0], c);
+      qw_vv0<DT, 0, 0>(acc[1], acc[0], c);                         // (no stores behind the pieces of the step before)
       set_step(s + 1);
-      qw_vv<DT, 4, 1>(acc[0], acc[1], c);
+      qw_vv1<DT, 0, 1>(acc[0], acc[1], c);
     }
     set_step(NIT - 1);
-    qw_v_<DT, 4, 0>(acc[1], acc[0], c);                            // epilogue of item 29 (behind a barrier: the next tile's first pieces
+    qw_v_<DT, 0, 0>(acc[1], acc[0], c);                            // epilogue of item 29 (behind a barrier: the next tile's first pieces
     g += QW_NCH;                                                   // overwrite chunk 14's slot); the next tile's rows go out before its stores
     if (!c.has_next) break;
     tile = next;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // rows + statistics landed; the 4 stores behind them may fly
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // rows + statistics landed; the 8 stores behind them may fly
   }
 }
 

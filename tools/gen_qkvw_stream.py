@@ -11,8 +11,9 @@ pipeline step s:
              chains, 40 MFMAs); five of the NEXT chunk's ten LDS-DMA pieces of the wave ride in front of / in its first gaps
     epilogue of item s: LayerNorm fold + bias, 16-bit, through the wave's LDS staging slot, 4 stores
 Chunks 0..9 are q | k columns (a lane owns a token, stores token-major rows of 128 B), chunks 10..14 V columns, computed with the
-MFMA operands swapped (a lane owns a channel and 32 tokens: V^T rows of 64 B).  Variants: pro (MFMA of chunk 0 only), qq, qv, vv,
-v_ (epilogue of chunk 14 only; it also fetches the next tile's rows BEFORE its stores).
+MFMA operands swapped (a lane owns a channel and 32 tokens; the wave's two row groups together hold 64 tokens of a channel: V^T
+rows of 128 B, stored by the second item of a chunk).  Variants: pro (MFMA of item 0 only), qq, qv, vv1 / vv0 (epilogue of the first
+/ second item of a V chunk), v_ (epilogue of the last item only; it also fetches the next tile's rows BEFORE its stores).
 
     python tools/gen_qkvw_stream.py            # rewrites the .inc (checked in; CPU test test_qkv320w_stream_is_current...)
 """
@@ -99,9 +100,13 @@ def epi_q():
     return it
 
 
-def epi_v():
-    """epilogue of a V item (a lane owns channel n, its registers the tokens 8 q + 4 hi + e): v = rstd[token] acc + d[n]"""
+def epi_v(second):
+    """epilogue of a V item (a lane owns channel n, its registers the tokens 8 q + 4 hi + e): v = rstd[token] acc + d[n].
+    The two row groups of a wave hold 64 consecutive tokens of a channel: the first item of a chunk (row group 0) only writes its
+    half of the staging image [32 channels][128 B], the second one writes the other half, reads the image back and stores whole
+    128-B lines of V^T (8 channel rows per instruction)."""
     it = []
+    rge = 1 if second else 0
     for f in range(2):
         it.append(("r", f"const float dn{f} = mw_lds32f<{128 * f}>(c.cdv);", [], f"dn{f}"))
         for q in range(4):
@@ -118,17 +123,17 @@ def epi_v():
             it.append(("s", f"mw_swap32(p{f}0{h}, p{f}2{h});", [], None))
         for h in range(2):
             it.append(("s", f"mw_swap32(p{f}1{h}, p{f}3{h});", [], None))
-        it.append(("l", f"mw_lds_write128<{2048 * f}>(c.vw[0], u32x4{{p{f}00, p{f}01, p{f}20, p{f}21}});", [], None))
-        it.append(("l", f"mw_lds_write128<{2048 * f}>(c.vw[1], u32x4{{p{f}10, p{f}11, p{f}30, p{f}31}});", [], None))
-    for f in range(2):
-        for i in range(2):
-            it.append(("l", f"const u32x4 o{f}{i} = mw_lds128<{2048 * f}>(c.vr[{i}]);", [], f"o{f}{i}"))
-    for f in range(2):
-        for i in range(2):
-            if "v" not in NO_STORE:
-                it.append(("s", f"mw_store128(c.vst[{i}], o{f}{i}, c.vtb[{f}]);", [f"o{f}{i}"], None))
-            else:
-                it.append(("s", f"asm volatile(\"\" :: \"v\"(o{f}{i}));", [f"o{f}{i}"], None))
+        it.append(("l", f"mw_lds_write128<{4096 * f}>(c.vw[{2 * rge}], u32x4{{p{f}00, p{f}01, p{f}20, p{f}21}});", [], None))
+        it.append(("l", f"mw_lds_write128<{4096 * f}>(c.vw[{2 * rge + 1}], u32x4{{p{f}10, p{f}11, p{f}30, p{f}31}});", [], None))
+    if second:
+        for f in range(2):
+            for i in range(4):
+                it.append(("l", f"const u32x4 o{f}{i} = mw_lds128<{4096 * f}>(c.qr[{i}]);", [], f"o{f}{i}"))
+            for i in range(4):
+                if "v" not in NO_STORE:
+                    it.append(("s", f"mw_store128(c.vstw[{i}], o{f}{i}, c.vtb[{f}]);", [f"o{f}{i}"], None))
+                else:
+                    it.append(("s", f"asm volatile(\"\" :: \"v\"(o{f}{i}));", [f"o{f}{i}"], None))
     return it
 
 
@@ -147,7 +152,7 @@ def build(name, epi, mf, top=True, xload=False):
     ngap = len(mfs)
     pieces = dma_pieces() if (mf and not NO_DMA) else []
     pre, rest = pieces[:PRE_DMA], pieces[PRE_DMA:]
-    items = (epi_q() if epi == "q" else epi_v()) if (epi and not NO_EPI) else []
+    items = (epi_q() if epi == "q" else epi_v(epi == "v2")) if (epi and not NO_EPI) else []
     # epilogue statements over the gaps behind the DMA pieces
     vgaps = list(range(min(len(rest), ngap), ngap))
     per_gap = {g: [] for g in range(ngap + 1)}
@@ -231,8 +236,9 @@ def main():
     parts.append(build("qw_pro", None, "q", top=False))
     parts.append(build("qw_qq", "q", "q"))
     parts.append(build("qw_qv", "q", "v"))
-    parts.append(build("qw_vv", "v", "v"))
-    parts.append(build("qw_v_", "v", None, xload=True))
+    parts.append(build("qw_vv1", "v1", "v"))        # epilogue of a chunk's first V item (row group 0): RGM = 1 only
+    parts.append(build("qw_vv0", "v2", "v"))        # epilogue of its second item: RGM = 0 only
+    parts.append(build("qw_v_", "v2", None, xload=True))
     txt = "\n\n".join(parts) + "\n"
     if "-o" in sys.argv:
         open(sys.argv[sys.argv.index("-o") + 1], "w").write(txt)

@@ -219,24 +219,33 @@ __global__ __launch_bounds__(256, 1) void qkv320w_kernel(const QwParams p, const
     qw_pro<DT, 0, 0>(acc[1], acc[0], c);                           // MFMAs of item 0 -> acc[0]; first half of chunk 1's pieces
     set_step(0);
     qw_qq<DT, 0, 1>(acc[0], acc[1], c);
-    for (int s = 1; s < QIT - 1; s += 2) {                         // steps 1 .. 18
+    // (VMC of a chunk-opening step = the stores issued since ITS pieces went out two steps earlier: 4 per q | k item)
+    set_step(1);
+    qw_qq<DT, 4, 0>(acc[1], acc[0], c);
+    set_step(2);
+    qw_qq<DT, 4, 1>(acc[0], acc[1], c);
+    for (int s = 3; s < QIT - 1; s += 2) {                         // steps 3 .. 18
       set_step(s);
-      qw_qq<DT, 4, 0>(acc[1], acc[0], c);
+      qw_qq<DT, 8, 0>(acc[1], acc[0], c);
       set_step(s + 1);
-      qw_qq<DT, 4, 1>(acc[0], acc[1], c);
+      qw_qq<DT, 8, 1>(acc[0], acc[1], c);
     }
     set_step(QIT - 1);
-    qw_qv<DT, 4, 0>(acc[1], acc[0], c);                            // epilogue of the last q | k item, MFMAs of the first V item
+    qw_qv<DT, 8, 0>(acc[1], acc[0], c);                            // epilogue of the last q | k item, MFMAs of the first V item
     set_step(QIT);
     qw_vv1<DT, 4, 1>(acc[0], acc[1], c);                           // (a V chunk's first item leaves its half of the V^T rows in LDS: no stores)
-    for (int s = QIT + 1; s < NIT - 1; s += 2) {                   // steps 21 .. 28
+    set_step(QIT + 1);
+    qw_vv0<DT, 4, 0>(acc[1], acc[0], c);                           // (behind chunk 11's pieces: the 4 stores of step 19, none of step 20)
+    set_step(QIT + 2);
+    qw_vv1<DT, 0, 1>(acc[0], acc[1], c);
+    for (int s = QIT + 3; s < NIT - 1; s += 2) {                   // steps 23 .. 28
       set_step(s);
-      qw_vv0<DT, 0, 0>(acc[1], acc[0], c);                         // (no stores behind the pieces of the step before)
+      qw_vv0<DT, 8, 0>(acc[1], acc[0], c);                         // (the 8 stores of the V chunk before)
       set_step(s + 1);
       qw_vv1<DT, 0, 1>(acc[0], acc[1], c);
     }
     set_step(NIT - 1);
-    qw_v_<DT, 0, 0>(acc[1], acc[0], c);                            // epilogue of item 29 (behind a barrier: the next tile's first pieces
+    qw_v_<DT, 8, 0>(acc[1], acc[0], c);                            // epilogue of item 29 (behind a barrier: the next tile's first pieces
     g += QW_NCH;                                                   // overwrite chunk 14's slot); the next tile's rows go out before its stores
     if (!c.has_next) break;
     tile = next;

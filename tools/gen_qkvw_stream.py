@@ -138,8 +138,12 @@ def epi_v(second):
 
 
 def dma_pieces():
-    """the wave's pieces (kt, u = RGM) of the next chunk: rows 8 (wave + 4 u) .. + 7 of K-tile kt"""
-    return [f"mw_dma<{kt * 8192} + RGM * 4096, {kt * 128}>(c.w1dst, c.w1_vj, c.w1b[RGM]);" for kt in range(5)]
+    """the wave's ten pieces (kt, u) of the next chunk: rows 8 (wave + 4 u) .. + 7 of K-tile kt -- all of them in the step that
+    opens a chunk (RGM == 0), right behind its barrier: loads and stores retire through ONE in-order counter, so a piece is only
+    known to have landed when every OLDER store has completed; issued early, the pieces have two steps' worth of stores behind
+    them and only the stores of three steps back in front (with five pieces per step the top wait sat behind the stores of
+    the step before: 100 us of a 395-us launch, NOTES_r06.md)"""
+    return [f"if constexpr (RGM == 0) mw_dma<{kt * 8192 + u * 4096}, {kt * 128}>(c.w1dst, c.w1_vj, c.w1b[{u}]);" for kt in range(5) for u in range(2)]
 
 
 def build(name, epi, mf, top=True, xload=False):

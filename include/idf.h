@@ -96,14 +96,18 @@ const char* idf_build_info(void);
  *   IDF_TUNE_QKV_ROW (round 6): the fused q | k | v projection of the C = 320 level (K = 320, N = 960, vt_col0 = 640, M % 128 == 0,
  *     statistics handed in) on qkv320w_kernel (activation rows resident in registers): 0 = never, 1 = when the shape qualifies
  *     (default).  Env IDF_QKV_ROW.
+ *   IDF_TUNE_GEGLU_ROW (round 6): the GEGLU projection of the C = 640 level (K = 640, N = 5120, epilogue BIAS | GEGLU | GEGLU_P32 |
+ *     LN_ROW with the statistics handed in, M % 128 == 0, from two tiles per CU) on geglu640w_kernel: 0 = never, 1 = when the shape
+ *     qualifies (default).  Env IDF_GEGLU_ROW.
  */
 enum { IDF_TUNE_GEMM_BIG = 0, IDF_TUNE_ATTN2 = 1, IDF_TUNE_GEMM_RING = 2, IDF_TUNE_BIG_MIN_EFF = 3, IDF_TUNE_ATTN8 = 4, IDF_TUNE_MLP = 5,
-       IDF_TUNE_QKV_ROW = 6 };
+       IDF_TUNE_QKV_ROW = 6, IDF_TUNE_GEGLU_ROW = 7 };
 int idf_set_tuning(int knob, int value);
 /* Process-global launch counters (tests assert which kernel served a call).  Unknown stat: -1. */
 enum { IDF_STAT_GEMM_BIG_LAUNCHES = 0, IDF_STAT_ATTN2_LAUNCHES = 1, IDF_STAT_GEMM_RING_LAUNCHES = 2, IDF_STAT_ATTN8_LAUNCHES = 3,
        IDF_STAT_GN_EPI_LAUNCHES = 4 /* idf_conv3x3 calls whose gn_partial came out of the conv epilogue, not the statistics pass */,
-       IDF_STAT_QKV_ROW_LAUNCHES = 6 /* fused q | k | v projections served by qkv320w_kernel (also counted in stat 0) */ };
+       IDF_STAT_QKV_ROW_LAUNCHES = 6 /* fused q | k | v projections served by qkv320w_kernel (also counted in stat 0) */,
+       IDF_STAT_GEGLU_ROW_LAUNCHES = 7 /* GEGLU projections served by geglu640w_kernel (also counted in stat 0) */ };
 long long idf_get_stat(int stat);
 
 /* ---- GEMM: out[M,N] = epi( A[M,K] . W[N,K]^T ) ----------------------------------------------------------

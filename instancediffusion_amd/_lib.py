@@ -13,8 +13,8 @@ LIB_PATH = os.environ.get("IDF_LIB_PATH", os.path.join(_HERE, "libidf_gfx950.so"
 
 IDF_BF16, IDF_F16 = 0, 1
 IDF_STAT_GEMM_BIG_LAUNCHES, IDF_STAT_ATTN2_LAUNCHES, IDF_STAT_GEMM_RING_LAUNCHES, IDF_STAT_ATTN8_LAUNCHES, IDF_STAT_GN_EPI_LAUNCHES = 0, 1, 2, 3, 4   # idf_get_stat
-IDF_STAT_QKV_ROW_LAUNCHES = 6
-IDF_TUNE_GEMM_BIG, IDF_TUNE_ATTN2, IDF_TUNE_GEMM_RING, IDF_TUNE_BIG_MIN_EFF, IDF_TUNE_ATTN8, IDF_TUNE_MLP, IDF_TUNE_QKV_ROW = 0, 1, 2, 3, 4, 5, 6      # idf_set_tuning
+IDF_STAT_QKV_ROW_LAUNCHES, IDF_STAT_GEGLU_ROW_LAUNCHES = 6, 7
+IDF_TUNE_GEMM_BIG, IDF_TUNE_ATTN2, IDF_TUNE_GEMM_RING, IDF_TUNE_BIG_MIN_EFF, IDF_TUNE_ATTN8, IDF_TUNE_MLP, IDF_TUNE_QKV_ROW, IDF_TUNE_GEGLU_ROW = 0, 1, 2, 3, 4, 5, 6, 7      # idf_set_tuning
 EPI_LN_ROW, EPI_LN_COL, EPI_GEGLU_P32 = 512, 1024, 2048
 EPI_BIAS, EPI_ROWBIAS, EPI_RES, EPI_GATE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_OUT_F32, EPI_OUT_NCHW = \
     1, 2, 4, 8, 16, 32, 64, 128, 256

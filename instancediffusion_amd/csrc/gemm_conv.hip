@@ -724,6 +724,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CoreParams p) 
 // grids of <= 256 tiles, where a launch is a chain of dependent trips to memory -- and is chosen by tile count in launch().
 std::atomic<long long> idf_stat_gn_epi_launches{0};   // idf_conv3x3 calls whose GroupNorm partials came out of the epilogue (idf_get_stat)
 std::atomic<long long> idf_stat_ring_launches{0};
+std::atomic<long long> idf_stat_gegluw_launches{0};   // GEGLU projections served by geglu640w_kernel (idf_get_stat)
 std::atomic<long long> idf_stat_qkvw_launches{0};     // fused q | k | v projections served by qkv320w_kernel (idf_get_stat)     // launches of the latency kernel (idf_get_stat)
 int g_big_mode = -2;
 inline int gemm_big_mode() {
@@ -950,6 +951,10 @@ extern "C" int idf_set_tuning(int knob, int value) {
     if (value < 0 || value > 6) return IDF_E_ARG;
     return idf_attn8_set_mode(value);
   }
+  if (knob == IDF_TUNE_GEGLU_ROW) {
+    if (value < 0 || value > 1) return IDF_E_ARG;
+    return idf_gegluw_set_mode(value);
+  }
   if (knob == IDF_TUNE_QKV_ROW) {
     if (value < 0 || value > 1) return IDF_E_ARG;
     return idf_qkvw_set_mode(value);
@@ -968,6 +973,7 @@ extern "C" long long idf_get_stat(int stat) {
   if (stat == IDF_STAT_ATTN8_LAUNCHES) return idf_stat_attn8_launches.load();
   if (stat == IDF_STAT_GN_EPI_LAUNCHES) return idf_stat_gn_epi_launches.load();
   if (stat == IDF_STAT_QKV_ROW_LAUNCHES) return idf_stat_qkvw_launches.load();
+  if (stat == IDF_STAT_GEGLU_ROW_LAUNCHES) return idf_stat_gegluw_launches.load();
   return -1;
 }
 
@@ -1062,6 +1068,11 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
   // the output as before
   int parts = 0;
   // (whether the workspace holds the [M][parts][2] partials is checked where `parts` is chosen: idf_launch_big)
+  if ((a->epi & IDF_EPI_GEGLU) && batch == 1 && !a->out_stats) {
+    // the row-resident GEGLU kernel of the C = 640 level (geglu_fused.hip); counted with the persistent-kernel launches
+    const int r = idf_launch_geglu640w(p, a->dtype, s);
+    if (r != IDF_BIG_UNSUPPORTED) { if (r == 0) { ++idf_stat_big_launches; ++idf_stat_gegluw_launches; } return r; }
+  }
   if (a->out_stats && batch == 1 && p.ws) p.stat_parts = p.ws;
   if (a->dtype == IDF_BF16) rc = launch<IDF_BF16, false>(p, batch, s, &parts);
   else if (a->dtype == IDF_F16) rc = launch<IDF_F16, false>(p, batch, s, &parts);

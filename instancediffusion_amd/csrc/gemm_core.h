@@ -142,6 +142,8 @@ extern std::atomic<long long> idf_stat_big_launches;     // process-global launc
 int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool force, hipStream_t s, int* splitk_out,
                    int* parts_out = nullptr, int* tail_m0_out = nullptr, int* gst_out = nullptr);
 int idf_launch_qkv320w(const idfcore::CoreParams& p, int dtype, hipStream_t s);   // qkv_fused.hip; IDF_BIG_UNSUPPORTED = not its shape
+int idf_launch_geglu640w(const idfcore::CoreParams& p, int dtype, hipStream_t s);   // geglu_fused.hip; IDF_BIG_UNSUPPORTED = not its shape
+int idf_gegluw_set_mode(int v);                         // 0 = never, 1 = when the shape qualifies; returns the previous mode
 int idf_qkvw_set_mode(int v);                           // 0 = never, 1 = when the shape qualifies; returns the previous mode
 int idf_mlp_set_mode(int v);                            // mlp_fused.hip: 0 = mlp320_kernel, 1 = mlp320w_kernel; returns the previous mode
 int idf_big_min_eff_pct(int set);                        // automatic rule's occupancy bar in per cent (set < 0: query)

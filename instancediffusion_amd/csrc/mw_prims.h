@@ -158,6 +158,16 @@ __device__ __forceinline__ float mw_fma(float a, float b, float c) {
   asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+__device__ __forceinline__ float mw_add(float a, float b) {
+  float d;
+  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float mw_mul(float a, float b) {
+  float d;
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 template <int OFF> __device__ __forceinline__ float mw_lds32f(unsigned addr) {
   float r;
   asm volatile("ds_read_b32 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF));

@@ -122,7 +122,7 @@ def test_argument_validation_without_gpu():
     assert lib.idf_groupnorm_apply(0x10000, 0x20008, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 0, None) == -2
     assert lib.idf_groupnorm_apply(0x10000, 0x20000, 0x30000, 0x40000, 0x50000, 1, 64, 320, 1, 1e-5, 1, 7, None) == -3
     # the pruned knobs are gone: unknown knob / value -> IDF_E_ARG, the remaining ones round-trip
-    assert lib.idf_set_tuning(7, 0) == -1 and lib.idf_set_tuning(1, 7) == -1 and lib.idf_set_tuning(0, 4) == -1      # (round 6: attention modes 4 / 5 = attention4w.hip, 6 = its persistent form in experiment builds)
+    assert lib.idf_set_tuning(8, 0) == -1 and lib.idf_set_tuning(1, 7) == -1 and lib.idf_set_tuning(0, 4) == -1      # (round 6: attention modes 4 / 5 = attention4w.hip, 6 = its persistent form in experiment builds)
     # round 5 (ABI 5): the d = 80 / 160 LDS-DMA attention kernel's knob and launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 7) == -1 and lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_ATTN8, 3)
@@ -138,6 +138,10 @@ def test_argument_validation_without_gpu():
     assert lib.idf_set_tuning(_lib.IDF_TUNE_QKV_ROW, 2) == -1 and lib.idf_get_stat(_lib.IDF_STAT_QKV_ROW_LAUNCHES) == 0
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_QKV_ROW, 0)
     assert prev == 1 and lib.idf_set_tuning(_lib.IDF_TUNE_QKV_ROW, prev) == 0
+    # ... and the GEGLU projection of the C = 640 level (geglu_fused.hip)
+    assert lib.idf_set_tuning(_lib.IDF_TUNE_GEGLU_ROW, 2) == -1 and lib.idf_get_stat(_lib.IDF_STAT_GEGLU_ROW_LAUNCHES) == 0
+    prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEGLU_ROW, 0)
+    assert prev == 1 and lib.idf_set_tuning(_lib.IDF_TUNE_GEGLU_ROW, prev) == 0
     # round 4: tile-count threshold of the latency kernel (0 = never), and its launch counter
     assert lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, -1) == -1
     prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEMM_RING, 77)
@@ -218,6 +222,12 @@ def test_mlp320w_stream_is_current_and_its_registers_are_left_alone():
     assert len(rep) == 2, sorted(rep)
     for name, r in rep.items():
         assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 200, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
+    # ... and geglu_fused.hip's row-resident GEGLU projection (x fragments a0..a159, statistics a160:161)
+    assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_gegluw_stream.py"), "--check"], env={k: v for k, v in os.environ.items() if not k.startswith("GW_")}).returncode == 0
+    rep = mod.check(src=os.path.join(REPO, "instancediffusion_amd", "csrc", "geglu_fused.hip"), kernel="geglu640w_kernel")
+    assert len(rep) == 2, sorted(rep)
+    for name, r in rep.items():
+        assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 100, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
 
 
 def test_schema_matches_reference():

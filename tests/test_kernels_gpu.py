@@ -1126,6 +1126,57 @@ def test_gemm_fused_qkv_transposed_v(ops, M, C, own):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [65536, 131072 + 128 * 5])
+def test_gemm_geglu_row_kernel(M, dtype):
+    """geglu_fused.hip: the GEGLU projection of the C = 640 level (K = 640, N = 5120, period-32 packing, LayerNorm folded, statistics
+    handed in) on the row-resident kernel (idf_gemm takes it from two 128-row tiles per CU up).  Against fp32 LN -> Linear ->
+    value * gelu(gate), against the persistent kernel on the same operands (the K sum runs as two partial sums and the fold is
+    fma-contracted: a small fraction of the outputs may differ by an ulp), every copy of a row bitwise equal whatever tile / wave
+    computed it, launch counted."""
+    import torch.nn.functional as F
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import pack_geglu
+    from instancediffusion_amd.ops import HipOps
+    ops = HipOps(dtype)
+    lib = _lib.load()
+    C, N = 640, 5120
+    gamma, beta = 1 + 0.2 * gen((C,), 501), 0.3 * gen((C,), 502)
+    rows = 2048
+    x = (gen((rows, C), 503) * 1.5 + 0.8 * gen((rows, 1), 504)).to(dtype)
+    x = x.repeat(M // rows + 1, 1)[:M].contiguous().cuda()
+    w, b = gen((N, C), 505, C ** -0.5), 0.2 * gen((N,), 506)
+    wp, dp = pack_geglu(w * gamma[None, :], b + w @ beta, 32)
+    w16 = wp.to(dtype).cuda()
+    c, d = w16.float().sum(1).contiguous(), dp.cuda()
+    st = ops.empty((M, 2), torch.float32)
+    ops.row_stats(x, st, 1e-5)
+    h = F.layer_norm(x[:rows].float(), (C,), gamma.cuda(), beta.cuda(), 1e-5) @ w.cuda().t() + b.cuda()
+    want = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+    outs = {}
+    for mode in (1, 0):
+        prev = lib.idf_set_tuning(_lib.IDF_TUNE_GEGLU_ROW, mode)
+        out = ops.empty((M, N // 2))
+        n0 = lib.idf_get_stat(_lib.IDF_STAT_GEGLU_ROW_LAUNCHES)
+        ops.gemm(x, w16, out, bias=d, geglu=True, geglu_period=32, ln_row=(st, c))
+        torch.cuda.synchronize()
+        served = lib.idf_get_stat(_lib.IDF_STAT_GEGLU_ROW_LAUNCHES) - n0
+        lib.idf_set_tuning(_lib.IDF_TUNE_GEGLU_ROW, prev)
+        assert served == mode
+        outs[mode] = out
+    out = outs[1]
+    tol = {torch.bfloat16: (BF16_TOL, BF16_TOL / 2), torch.float16: (2.0 ** -9, 2.0 ** -10)}[dtype]
+    err, mx = rel_rms(out[:rows], want), relmax(out[:rows], want)
+    err0 = rel_rms(outs[0][:rows], want)
+    both = rel_rms(out, outs[0])
+    nd = float((out != outs[0]).float().mean())
+    print(f"[parity] GEGLU row kernel M{M} {dtype}: rel-rms {err:.3e} (persistent kernel {err0:.3e}) max-rel {mx:.3e}; vs persistent kernel "
+          f"rel-rms {both:.2e}, differing elements {nd:.2e}")
+    assert mx < tol[0] and err < tol[1] and err < 1.05 * err0 + 1e-5
+    assert both < 2e-4 and nd < 2e-2
+    assert torch.equal(out[:rows], out[rows:2 * rows]) and torch.equal(out[:rows], out[M - (M % rows or rows) - rows:][:rows])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [131072, 262144 + 256 * 7])
 def test_gemm_fused_qkv_row_kernel(M, dtype):
     """qkv_fused.hip: the fused q | k | v projection of the C = 320 level on the row-resident kernel (idf_gemm with vt_out takes it

@@ -93,9 +93,10 @@ const char* idf_build_info(void);
  *   Initial value: env IDF_ATTN8 or the default (1).
  *   IDF_TUNE_MLP (round 6; a knob id, no new entry point): idf_mlp_geglu on 0 = mlp320_kernel (8 waves, two per SIMD),
  *     1 = mlp320w_kernel (4 waves, one generated instruction stream per SIMD; default).  Same results bit for bit.  Env IDF_MLP_MODE.
- *   IDF_TUNE_QKV_ROW (round 6): the fused q | k | v projection of the C = 320 level (K = 320, N = 960, vt_col0 = 640, M % 128 == 0,
- *     statistics handed in) on qkv320w_kernel (activation rows resident in registers): 0 = never, 1 = when the shape qualifies
- *     (default).  Env IDF_QKV_ROW.
+ *   IDF_TUNE_QKV_ROW (round 6): the fused q | k | v projection of the C = 320 level (K = 320, N = 960, vt_col0 = 640, M % 256 == 0) and
+ *     of the C = 640 level (K = 640, N = 1920, vt_col0 = 1280, M % 128 == 0), statistics handed in, from two tiles per CU, on
+ *     qkv320w_kernel / qkv640w_kernel (activation rows resident in registers): 0 = never, 1 = when the shape qualifies (default).
+ *     Env IDF_QKV_ROW.
  *   IDF_TUNE_GEGLU_ROW (round 6): the GEGLU projection of the C = 640 level (K = 640, N = 5120, epilogue BIAS | GEGLU | GEGLU_P32 |
  *     LN_ROW with the statistics handed in, M % 128 == 0, from two tiles per CU) on geglu640w_kernel: 0 = never, 1 = when the shape
  *     qualifies (default).  Env IDF_GEGLU_ROW.

@@ -10,10 +10,10 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-resul
 mkdir -p build
 OBJS=""
 PIDS=""
-for f in gemm_conv gemm_big mlp_fused qkv_fused geglu_fused attention attention4 attention4w attention8 norms scaleu misc convnext; do
+for f in gemm_conv gemm_big mlp_fused qkv_fused qkv640_fused geglu_fused attention attention4 attention4w attention8 norms scaleu misc convnext; do
   stale=0
   [ -f build/$f.o ] || stale=1
-  for dep in $f.hip common.h gemm_core.h attn_core.h mw_prims.h mlpw_stream.inc qkvw_stream.inc gegluw_stream.inc ../../include/idf.h; do
+  for dep in $f.hip common.h gemm_core.h attn_core.h mw_prims.h mlpw_stream.inc qkvw_stream.inc gegluw_stream.inc qkv640w_stream.inc ../../include/idf.h; do
     [ $dep -nt build/$f.o ] && stale=1
   done
   if [ $stale = 1 ]; then

@@ -1036,7 +1036,8 @@ extern "C" int idf_gemm(const idf_gemm_args* a, void* stream) {
     if (self_ln && !a->ln_stats_out) return IDF_E_ARG;        // the fallback's second GEMM needs them somewhere
     p.vt_out = (unsigned short*)a->vt_out; p.ld_vt = a->ld_vt; p.vt_col0 = a->vt_col0;
     {   // the row-resident kernel of the C = 320 level (qkv_fused.hip); counted with the persistent-kernel launches
-      const int r = idf_launch_qkv320w(p, a->dtype, s);
+      int r = idf_launch_qkv320w(p, a->dtype, s);
+      if (r == IDF_BIG_UNSUPPORTED) r = idf_launch_qkv640w(p, a->dtype, s);       // ... and of the C = 640 level (qkv640_fused.hip)
       if (r != IDF_BIG_UNSUPPORTED) { if (r == 0) { ++idf_stat_big_launches; ++idf_stat_qkvw_launches; } return r; }
     }
     if (gemm_big_mode() > 0) {

@@ -144,6 +144,8 @@ int idf_launch_big(const idfcore::CoreParams& p, int dtype, bool conv, bool forc
 int idf_launch_qkv320w(const idfcore::CoreParams& p, int dtype, hipStream_t s);   // qkv_fused.hip; IDF_BIG_UNSUPPORTED = not its shape
 int idf_launch_geglu640w(const idfcore::CoreParams& p, int dtype, hipStream_t s);   // geglu_fused.hip; IDF_BIG_UNSUPPORTED = not its shape
 int idf_gegluw_set_mode(int v);                         // 0 = never, 1 = when the shape qualifies; returns the previous mode
+int idf_launch_qkv640w(const idfcore::CoreParams& p, int dtype, hipStream_t s);   // qkv640_fused.hip
+int idf_qkv640w_set_mode(int v);
 int idf_qkvw_set_mode(int v);                           // 0 = never, 1 = when the shape qualifies; returns the previous mode
 int idf_mlp_set_mode(int v);                            // mlp_fused.hip: 0 = mlp320_kernel, 1 = mlp320w_kernel; returns the previous mode
 int idf_big_min_eff_pct(int set);                        // automatic rule's occupancy bar in per cent (set < 0: query)

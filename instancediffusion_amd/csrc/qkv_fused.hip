@@ -276,6 +276,7 @@ inline int qkvw_mode() {
 int idf_qkvw_set_mode(int v) {
   const int prev = qkvw_mode();
   g_qkvw_mode = v;
+  idf_qkv640w_set_mode(v);                         // one knob for both levels
   return prev;
 }
 

@@ -222,6 +222,12 @@ def test_mlp320w_stream_is_current_and_its_registers_are_left_alone():
     assert len(rep) == 2, sorted(rep)
     for name, r in rep.items():
         assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 200, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
+    # ... qkv640_fused.hip (the C = 640 level's q | k | v projection on geglu_fused.hip's skeleton)
+    assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_qkv640w_stream.py"), "--check"], env={k: v for k, v in os.environ.items() if not k.startswith("QM_")}).returncode == 0
+    rep = mod.check(src=os.path.join(REPO, "instancediffusion_amd", "csrc", "qkv640_fused.hip"), kernel="qkv640w_kernel")
+    assert len(rep) == 2, sorted(rep)
+    for name, r in rep.items():
+        assert not r["stray_accvgpr"] and r["scratch_ops"] == 0 and r["mfma"] > 100, (name, r["stray_accvgpr"][:3], r["scratch_ops"])
     # ... and geglu_fused.hip's row-resident GEGLU projection (x fragments a0..a159, statistics a160:161)
     assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_gegluw_stream.py"), "--check"], env={k: v for k, v in os.environ.items() if not k.startswith("GW_")}).returncode == 0
     rep = mod.check(src=os.path.join(REPO, "instancediffusion_amd", "csrc", "geglu_fused.hip"), kernel="geglu640w_kernel")

@@ -1177,10 +1177,10 @@ def test_gemm_geglu_row_kernel(M, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [131072, 262144 + 256 * 7])
-def test_gemm_fused_qkv_row_kernel(M, dtype):
-    """qkv_fused.hip: the fused q | k | v projection of the C = 320 level on the row-resident kernel (idf_gemm with vt_out takes it
-    from two 256-row tiles per CU up when the statistics are handed in).  Against fp32 LayerNorm -> Linear, against the persistent
+@pytest.mark.parametrize("M,C", [(131072, 320), (262144 + 256 * 7, 320), (65536, 640), (131072 + 128 * 3, 640)])
+def test_gemm_fused_qkv_row_kernel(M, C, dtype):
+    """qkv_fused.hip / qkv640_fused.hip: the fused q | k | v projection of the C = 320 / C = 640 level on the row-resident kernels
+    (idf_gemm with vt_out takes them from two 256- / 128-row tiles per CU up when the statistics are handed in).  Against fp32 LayerNorm -> Linear, against the persistent
     kernel on the same operands (the mean term of the fold rides the MFMAs as 16-bit hi + lo products: a fraction of the outputs may
     differ by one ulp, no more), every copy of a row bitwise equal whatever tile / wave / row group computed it, launch counted; and
     exact data with the identity fold ((mu, rstd) = (0, 1), c = d = 0) must equal the plain product bit for bit."""
@@ -1189,7 +1189,6 @@ def test_gemm_fused_qkv_row_kernel(M, dtype):
     from instancediffusion_amd.ops import HipOps
     ops = HipOps(dtype)
     lib = _lib.load()
-    C = 320
     gamma, beta = 1 + 0.2 * gen((C,), 401), 0.3 * gen((C,), 402)
     rows = 4096
     x = (gen((rows, C), 403) * 1.5 + 0.8 * gen((rows, 1), 404)).to(dtype)

@@ -14,7 +14,7 @@ from instancediffusion_amd.ops import HipOps  # noqa: E402
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[sys.argv[2] if len(sys.argv) > 2 else "bf16"]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-C = 320
+C = int(os.environ.get("QKV_C", "320"))
 ops = HipOps(dtype)
 lib = _lib.load()
 g = torch.Generator().manual_seed(5)
@@ -53,7 +53,7 @@ for mode in (0, 1):
     same_rows = bool(torch.equal(qk[:rows], qk[rows:2 * rows]) and torch.equal(vt[:, :rows], vt[:, rows:2 * rows])) if M >= 2 * rows else None
     fin = bool(torch.isfinite(qk.float()).all() and torch.isfinite(vt.float()).all())
     print(f"mode {mode}: served by qkv320w {served}; q|k rel-rms {eq:.3e}, V^T rel-rms {ev:.3e}; copies of a row bitwise equal {same_rows}; finite {fin}; "
-          f"{min(ts):.1f} us ({2.0 * M * 960 * 320 / min(ts) * 1e-6:.1f} TF)  runs {['%.1f' % t for t in ts]}")
+          f"{min(ts):.1f} us ({2.0 * M * 3 * C * C / min(ts) * 1e-6:.1f} TF)  runs {['%.1f' % t for t in ts]}")
     outs[mode] = (qk, vt)
 dq = float((outs[0][0].float() - outs[1][0].float()).abs().max()); dv = float((outs[0][1].float() - outs[1][1].float()).abs().max())
 nq = float((outs[0][0] != outs[1][0]).float().mean()); nv = float((outs[0][1] != outs[1][1]).float().mean())

@@ -200,8 +200,9 @@ def measure_roofline(engine, batch, fuser_on=True):
                        "gemm_kernel_ring<..,true> + split-K for small grids)",
             "gemm": "gemm_kernel_big<.., CONV=false> (persistent 256x{320,256}-tile dense GEMM, LDS-DMA staging, in-register "
                     "epilogue; gemm_kernel_ring / gemm_kernel_dma 128x128 for small grids and batched launches) + mlp320w_kernel (the C = 320 GEGLU "
-                    "feed-forwards, both products in one launch, one generated instruction stream per SIMD) + qkv320w_kernel (the fused "
-                    "q | k | v projections of the C = 320 level, activation rows resident in registers)",
+                    "feed-forwards, both products in one launch, one generated instruction stream per SIMD) + qkv320w_kernel / qkv640w_kernel / "
+                    "geglu640w_kernel (the fused q | k | v projections of the C = 320 / 640 levels and the GEGLU projection of the C = 640 "
+                    "level, activation rows resident in registers)",
             "attention": "attn4w_kernel<DT,2> for d=40 (64 queries/wave, asm-scheduled stream, LDS-DMA K / V^T rings, max-free softmax, XCD-aware "
                          "grid) / attn8_kernel for d=80,160 (32 queries/wave, LDS-DMA rings, deferred-rescale running max) / "
                          "attn_kernel for the 77-key cross-attention"

@@ -37,7 +37,7 @@ def family(name):
         return "attention"
     if "splitk_reduce" in name:
         return "conv3x3"                         # only the 8x8-level convs / ff-out GEMMs split K; booked with the convs
-    if "mlp320" in name or "qkv320w" in name:    # the fused GEGLU feed-forward (mlp320_kernel / mlp320w_kernel), the row-resident q | k | v projection
+    if any(k in name for k in ("mlp320", "qkv320w", "qkv640w", "geglu640w")):    # the fused GEGLU feed-forward and the row-resident projection kernels
         return "gemm"
     if "gemm_kernel_big" in name:                # <DT, BM, BN, BKT, NSTG, CONV, SPLIT>
         a = _targs(name)

@@ -11,21 +11,25 @@
 //     and half the barriers per flop of the first, one-group build (2 400 issue cycles per 1 280 of matrix pipe, 600 of them
 //     LDS-DMA issue: profiles/NOTES_r06.md);
 //   * the [960][320] weight image streams through a 2-slot LDS ring in 15 chunks of 64 rows by LDS-DMA (the fused MLP's W1
-//     chunk geometry: same piece roles, same swizzle, same fragment reads), one barrier per chunk;
-//   * per pipeline step: 40 MFMAs of chunk i + 1 (two independent 32 x 32 chains) carry the epilogue of chunk i in their gaps --
-//     LayerNorm fold + bias in fp32, 16-bit, through a wave-private LDS staging slot so that a store instruction writes whole
-//     lines (8 rows x 128 B of q | k, 16 rows x 64 B of V^T), 4 stores per chunk -- as a GENERATED `asm volatile` stream
-//     (tools/gen_qkvw_stream.py -> qkvw_stream.inc; primitives mw_prims.h);
-//   * V chunks (columns 640 ..) run with the MFMA operands swapped, so a lane owns a channel and its registers the wave's 32
-//     tokens: after two v_permlane32_swap per register pair a lane holds 16 consecutive tokens of its channel;
+//     chunk geometry: same piece roles, same swizzle, same fragment reads), one barrier per chunk, all ten pieces of a wave
+//     in the step that opens the chunk;
+//   * per pipeline step: the 42 MFMAs of an item (two independent 32 x 32 chains of 20 k-steps + the mean term's k-step) carry
+//     the epilogue of the item before in their gaps -- rstd . acc + d in fp32, 16-bit, through a wave-private LDS staging slot so
+//     that a store instruction writes whole 128-B lines (8 token rows of q | k, 8 channel rows of V^T) -- as a GENERATED
+//     `asm volatile` stream (tools/gen_qkvw_stream.py -> qkvw_stream.inc; primitives mw_prims.h);
+//   * V chunks (columns 640 ..) run with the MFMA operands swapped, so a lane owns a channel and its registers 32 tokens of a row
+//     group: after two v_permlane32_swap per register pair a lane holds 16 consecutive tokens of its channel; the chunk's first
+//     item leaves its half of the V^T rows in the staging image, the second stores the 64-token rows;
 //   * the next tile's rows are fetched in the last step of a tile BEFORE its stores, and every top-of-step wait is a counted
 //     vmcnt: the stream never waits for a store round trip.
+// What bounds it (profiles/NOTES_r06.md section 5): 395 us per launch at 128 rows against 296 with the stores compiled out and
+// 530-557 on the persistent kernel -- 1.0 GB written at 2.56 TB/s next to 0.34 GB read.
 // Taken by idf_gemm when K = 320, N = 960, vt_col0 = 640, M % 256 == 0, M >= 2 x 256 x (number of CUs), LN_ROW with the
 // statistics handed in (ln_stats != NULL) and BIAS; everything else stays on gemm_big.hip.  Same arithmetic per output element
 // (fp32 accumulation over k = 0 .. 319 in the same order), except that the mean term -mu c[n] rides the MFMAs as a 21st k-step of
 // four 16-bit products (c and -mu split hi + lo, 2^-17 each) instead of an fp32 fma per element: measured error against fp64
 // identical to the persistent kernel's (1.66e-3 bf16 / 2.07e-4 fp16 rel-RMS), 0.1 % of the outputs differ by one 16-bit ulp.
-// LDS: 2 x 40 KB ring + 7.5 KB (c | d of all 960 columns) + 1 KB (the waves' (-mu, rstd) tables) + 4 x 4 KB staging = 105 KB.
+// LDS: 2 x 40 KB ring + 15.5 KB (the c table as 16-bit hi | lo pairs) + 3.75 KB (d) + 1 KB (the waves' rstd tables) + 4 x 8 KB staging = 132 KB.
 #include "gemm_core.h"
 #include "mw_prims.h"
 #include <cstdlib>

@@ -1031,6 +1031,43 @@ def test_gemm_fused_mlp(M, gated, inplace, dtype):
         assert torch.equal(out[:rows], out[rows:2 * rows]) and torch.equal(out[:128], out[M - (M % rows or rows):][:128])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,gated", [(128, True), (65536 + 128, False), (524288, True)])
+def test_gemm_fused_mlp_stream_kernel_is_bit_identical(M, gated, dtype):
+    """mlp320w_kernel (one generated instruction stream per SIMD, the default of idf_mlp_geglu since round 6) computes the same sums in
+    the same order as mlp320_kernel (IDF_TUNE_MLP = 0): the two outputs must agree BIT FOR BIT, in place as the engine calls it --
+    which also keeps the rounds 4-5 kernel under test."""
+    from instancediffusion_amd import _lib
+    from instancediffusion_amd.engine import pack_geglu
+    from instancediffusion_amd.ops import HipOps
+    ops = HipOps(dtype)
+    lib = _lib.load()
+    C, Hd = 320, 1280
+    gamma, beta = 1 + 0.2 * gen((C,), 601), 0.3 * gen((C,), 602)
+    w1, b1 = gen((2 * Hd, C), 603, C ** -0.5), 0.2 * gen((2 * Hd,), 604)
+    w2, b2 = gen((C, Hd), 605, Hd ** -0.5), 0.2 * gen((C,), 606)
+    rows = min(M, 8192)
+    x = (gen((rows, C), 607) * 1.5 + 0.5 * gen((rows, 1), 608)).to(dtype)
+    x = x.repeat(M // rows + 1, 1)[:M].contiguous().cuda()
+    gate = torch.tensor([0.6], dtype=torch.float32).cuda() if gated else None
+    wp, dp = pack_geglu(w1 * gamma[None, :], b1 + w1 @ beta, 32)
+    w1_16, w2_16 = wp.to(dtype).cuda(), w2.to(dtype).cuda()
+    c1 = w1_16.float().sum(1).contiguous()
+    cd, w2p = ops.mlp_pack(w1_16, c1, dp.cuda(), w2_16)
+    st = ops.empty((M, 2), torch.float32)
+    ops.row_stats(x, st, 1e-5)
+    outs = {}
+    for mode in (0, 1):
+        prev = lib.idf_set_tuning(_lib.IDF_TUNE_MLP, mode)
+        xin = x.clone()
+        ops.mlp_geglu(xin, st, w1_16, cd, w2p, b2.cuda(), xin, gate=gate)
+        torch.cuda.synchronize()
+        lib.idf_set_tuning(_lib.IDF_TUNE_MLP, prev)
+        outs[mode] = xin
+    assert torch.isfinite(outs[1].float()).all() and not torch.equal(outs[1], x)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("ratio", [10.0, 100.0])
 def test_gemm_layernorm_self_stats_large_mean_bound(ops, ratio):
     """the in-loop row sums of the persistent kernel are single-pass (sum x, sum x^2 by v_dot2c, fp32), so a row

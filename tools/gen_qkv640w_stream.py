@@ -2,7 +2,7 @@
 (qkv640_fused.hip: the fused q | k | v projection of a C = 640 transformer block with the activation rows resident in registers;
 the skeleton of geglu640w_kernel -- tools/gen_gegluw_stream.py -- with the epilogues of qkv320w_kernel).
 
-Same rules as tools/gen_mlpw_stream.py.  One pipeline step i of a 128-row tile (60 chunks of 32 W rows: 40 of q | k columns, 20 of V):
+The scheduler and its rules: tools/mw_streamgen.py.  One pipeline step i of a 128-row tile (60 chunks of 32 W rows: 40 of q | k columns, 20 of V):
     top      s_waitcnt vmcnt(VMC) + s_barrier: the ten LDS-DMA pieces of step i - 1 (W chunk i + 1) landed; the VMC stores issued
              behind them may still be in flight
     MFMA     first product of chunk i + 1: ONE 32 x 32 fragment, K = 640 = 40 k-steps on two accumulators (even / odd k-steps); V
@@ -16,7 +16,8 @@ qm_vv, qm_last (epilogue of the last V chunk; it also fetches the next tile's ro
     python tools/gen_qkv640w_stream.py            # rewrites the .inc (checked in; CPU test in tests/test_capi.py)
 """
 import os
-import sys
+
+from mw_streamgen import ARGS, finish, header, schedule
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "instancediffusion_amd", "csrc", "qkv640w_stream.inc")
@@ -25,33 +26,6 @@ PRE_DMA = int(os.environ.get("QM_PRE_DMA", 3))
 MAXV = int(os.environ.get("QM_MAXV", 6))
 NO_EPI = os.environ.get("QM_NO_EPI") == "1"       # timing experiments (wrong results)
 NO_DMA = os.environ.get("QM_NO_DMA") == "1"
-
-
-class Stream:
-    """statements in issue order; LDS operations (reads AND writes) are counted: a wait for read r is lgkmcnt(issued - seq(r) - 1)"""
-
-    def __init__(self):
-        self.lines, self.issued, self.done, self.seq = [], 0, 0, {}
-
-    def lds(self, code, name=None):
-        self.lines.append("  " + code)
-        if name:
-            self.seq[name] = self.issued
-        self.issued += 1
-
-    def wait(self, name):
-        s = self.seq[name]
-        if s < self.done:
-            return
-        n = self.issued - s - 1
-        assert 0 <= n <= 15, (name, n)
-        self.lines.append(f"  mw_wait_lgkm<{n}>();")
-        self.done = s + 1
-
-    def stmt(self, code, needs=()):
-        for r in needs:
-            self.wait(r)
-        self.lines.append("  " + code)
 
 
 def mf_items(kind):
@@ -131,102 +105,23 @@ def dma_pieces():
 
 def build(name, epi, mf, store, top=True, xload=False):
     """epi: None / "q" / "v"; mf: None / "q" / "v" """
-    st = Stream()
-    args = "f32x16 (&accC)[2], f32x16 (&accN)[2], const QmCtx& c"
-    st.lines.append(f"template <int DT, int VMC> __device__ __forceinline__ void {name}({args}) {{")
-    if top:
-        st.lines.append("  mw_wait_vm_barrier<VMC>();")
-    mfs = mf_items(mf) if mf else []
-    ngap = len(mfs)
-    pieces = dma_pieces() if (mf and not NO_DMA) else []
-    pre, rest = pieces[:PRE_DMA], pieces[PRE_DMA:]
+    decl = f"template <int DT, int VMC> __device__ __forceinline__ void {name}({ARGS.format(ctx='QmCtx')})"
+    xl = ("if (c.has_next) { mw_static_for<40>([&](auto kc) { mw_load_x2<decltype(kc)::value, decltype(kc)::value>(c.xnext); }); "
+          "asm volatile(\"global_load_dwordx2 a[160:161], %0, off\" ::\"v\"(c.snext) : \"memory\"); }")
     items = (epi_q(store) if epi == "q" else epi_v()) if (epi and not NO_EPI) else []
-    vgaps = list(range(min(len(rest), ngap), ngap))
-    per_gap = {g: [] for g in range(ngap + 1)}
-    n_under = min(len(items), MAXV * len(vgaps))
-    for k in range(n_under):
-        per_gap[vgaps[k * len(vgaps) // n_under]].append(items[k])
-    for k in range(n_under, len(items)):
-        per_gap[ngap].append(items[k])
-    hoist = []
-    for g, (_, rn, rc) in enumerate(mfs):
-        hoist.append((g, 1, rc, rn, LA))
-    for g in range(ngap + 1):
-        for kind, code, needs, defs in per_gap[g]:
-            if kind == "r":
-                hoist.append((g, 0, code, defs, min(LA, 2)))
-    hoist.sort(key=lambda h: (h[0], h[1]))
-    hp = [0]
-
-    def issue_upto(gap):
-        while hp[0] < len(hoist):
-            need, _, code, rn, ahead = hoist[hp[0]]
-            if need - ahead > gap or st.issued - st.done >= 13:
-                break
-            st.lds(code, rn)
-            hp[0] += 1
-
-    def force(rn):
-        while rn not in st.seq:
-            need, _, code, r2, ahead = hoist[hp[0]]
-            st.lds(code, r2)
-            hp[0] += 1
-
-    def emit(kind, ecode, needs, defs):
-        if kind == "r":
-            return
-        for r in needs:
-            force(r)
-        if kind == "l":
-            for r in needs:
-                st.wait(r)
-            st.lds(ecode, defs)
-        else:
-            st.stmt(ecode, needs)
-
-    if xload:
-        st.lines.append("  if (c.has_next) { mw_static_for<40>([&](auto kc) { mw_load_x2<decltype(kc)::value, decltype(kc)::value>(c.xnext); }); "
-                        "asm volatile(\"global_load_dwordx2 a[160:161], %0, off\" ::\"v\"(c.snext) : \"memory\"); }")
-    issue_upto(0)
-    for s in pre:
-        st.lines.append("  " + s)
-    for g in range(ngap):
-        code, rn, _ = mfs[g]
-        issue_upto(g)
-        force(rn)
-        st.stmt(code, [rn])
-        issue_upto(g + 1)
-        if g < len(rest):
-            st.lines.append("  " + rest[g])
-        for it in per_gap[g]:
-            emit(*it)
-    for s in rest[ngap:]:
-        st.lines.append("  " + s)
-    for it in per_gap[ngap]:
-        emit(*it)
-    assert hp[0] == len(hoist), (name, hp[0], len(hoist))
-    st.lines.append("}")
-    return "\n".join(st.lines)
+    return schedule(decl, mf_items(mf) if mf else [], dma_pieces() if (mf and not NO_DMA) else [], items, LA, PRE_DMA, MAXV,
+                    top="mw_wait_vm_barrier<VMC>();" if top else None, xload=xl if xload else None)
 
 
 def main():
-    parts = ["// GENERATED by tools/gen_qkv640w_stream.py -- do not edit; see that script for the schedule rules.",
-             f"// LA = {LA} gaps of LDS-read lookahead, {PRE_DMA} LDS-DMA pieces in front of the first MFMA, <= {MAXV} epilogue statements per gap.", ""]
+    parts = header("gen_qkv640w_stream.py", LA, PRE_DMA, MAXV)
     parts.append(build("qm_pro", None, "q", False, top=False))
     parts.append(build("qm_qq", "q", "q", False))
     parts.append(build("qm_qq_st", "q", "q", True))
     parts.append(build("qm_qv_st", "q", "v", True))
     parts.append(build("qm_vv", "v", "v", True))
     parts.append(build("qm_last", "v", None, True, xload=True))
-    txt = "\n\n".join(parts) + "\n"
-    if "-o" in sys.argv:
-        open(sys.argv[sys.argv.index("-o") + 1], "w").write(txt)
-        return
-    if "--check" in sys.argv:
-        cur = open(OUT).read() if os.path.exists(OUT) else ""
-        sys.exit(0 if cur == txt else 1)
-    open(OUT, "w").write(txt)
-    print("wrote", OUT, len(txt.split("\n")), "lines")
+    finish(parts, OUT)
 
 
 if __name__ == "__main__":

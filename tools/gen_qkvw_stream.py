@@ -1,8 +1,7 @@
 """Generator of instancediffusion_amd/csrc/qkvw_stream.inc: the straight-line instruction streams of qkv320w_kernel
 (qkv_fused.hip: the fused q | k | v projection of a C = 320 transformer block with the activation rows resident in registers).
 
-Same rules as tools/gen_mlpw_stream.py (every statement `asm volatile`, LDS reads LA gaps ahead of their consumers in FIFO order
-with counted lgkmcnt waits -- LDS WRITES count too, they retire in the same queue).  A wave owns TWO groups of 32 rows of a 256-row tile; a work item = (W chunk, row group), 30 per tile, chunk-major, so that a
+The scheduler and its rules: tools/mw_streamgen.py.  A wave owns TWO groups of 32 rows of a 256-row tile; a work item = (W chunk, row group), 30 per tile, chunk-major, so that a
 chunk stays in LDS for both row groups (half the LDS-DMA pieces and half the barriers per flop of a one-group tile).  One
 pipeline step s:
     top      (steps whose MFMAs start a new chunk: RGM == 0) s_waitcnt vmcnt(VMC) + s_barrier: the chunk's LDS-DMA pieces landed;
@@ -18,7 +17,8 @@ rows of 128 B, stored by the second item of a chunk).  Variants: pro (MFMA of it
     python tools/gen_qkvw_stream.py            # rewrites the .inc (checked in; CPU test test_qkv320w_stream_is_current...)
 """
 import os
-import sys
+
+from mw_streamgen import ARGS, finish, header, schedule
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "instancediffusion_amd", "csrc", "qkvw_stream.inc")
@@ -28,33 +28,6 @@ MAXV = int(os.environ.get("QW_MAXV", 6))          # epilogue statements per MFMA
 NO_EPI = os.environ.get("QW_NO_EPI") == "1"       # timing experiments (wrong results)
 NO_DMA = os.environ.get("QW_NO_DMA") == "1"
 NO_STORE = os.environ.get("QW_NO_STORE", "")      # "q" / "v" / "qv": the q | k / V^T stores left out (timing experiments)
-
-
-class Stream:
-    """statements in issue order; LDS operations are counted so that a wait for read r is lgkmcnt(issued - seq(r) - 1)"""
-
-    def __init__(self):
-        self.lines, self.issued, self.done, self.seq = [], 0, 0, {}
-
-    def lds(self, code, name=None):
-        self.lines.append("  " + code)
-        if name:
-            self.seq[name] = self.issued
-        self.issued += 1
-
-    def wait(self, name):
-        s = self.seq[name]
-        if s < self.done:
-            return
-        n = self.issued - s - 1
-        assert 0 <= n <= 15, (name, n)
-        self.lines.append(f"  mw_wait_lgkm<{n}>();")
-        self.done = s + 1
-
-    def stmt(self, code, needs=()):
-        for r in needs:
-            self.wait(r)
-        self.lines.append("  " + code)
 
 
 def mf_items(kind):
@@ -147,111 +120,25 @@ def dma_pieces():
 
 
 def build(name, epi, mf, top=True, xload=False):
-    st = Stream()
-    args = "f32x16 (&accC)[2], f32x16 (&accN)[2], const QwCtx& c"
-    st.lines.append(f"template <int DT, int VMC, int RGM> __device__ __forceinline__ void {name}({args}) {{")
-    if top:
-        st.lines.append("  if constexpr (RGM == 0) mw_wait_vm_barrier<VMC>();")
-    mfs = mf_items(mf) if mf else []
-    ngap = len(mfs)
-    pieces = dma_pieces() if (mf and not NO_DMA) else []
-    pre, rest = pieces[:PRE_DMA], pieces[PRE_DMA:]
+    """epi: None / "q" / "v1" / "v2" (first / second item of a V chunk); mf: None / "q" / "v" """
+    decl = f"template <int DT, int VMC, int RGM> __device__ __forceinline__ void {name}({ARGS.format(ctx='QwCtx')})"
+    xl = ("if (c.has_next) { mw_static_for<20>([&](auto kc) { mw_load_x2<decltype(kc)::value, decltype(kc)::value>(c.xnext); "
+          "mw_load_x2<20 + decltype(kc)::value, decltype(kc)::value>(c.xnext2); }); "
+          "asm volatile(\"global_load_dwordx2 a[168:169], %0, off\\n\\tglobal_load_dwordx2 a[170:171], %0, off offset:256\" ::\"v\"(c.snext) : \"memory\"); }")
     items = (epi_q() if epi == "q" else epi_v(epi == "v2")) if (epi and not NO_EPI) else []
-    # epilogue statements over the gaps behind the DMA pieces
-    vgaps = list(range(min(len(rest), ngap), ngap))
-    per_gap = {g: [] for g in range(ngap + 1)}
-    n_under = min(len(items), MAXV * len(vgaps))
-    for k in range(n_under):
-        per_gap[vgaps[k * len(vgaps) // n_under]].append(items[k])
-    for k in range(n_under, len(items)):
-        per_gap[ngap].append(items[k])
-    # hoistable reads: a fragment read LA gaps ahead of its MFMA; a constant read 2 gaps ahead of the gap of its first use
-    hoist = []                              # (need gap, order, code, name)
-    for g, (_, rn, rc) in enumerate(mfs):
-        hoist.append((g, 1, rc, rn, LA))
-    for g in range(ngap + 1):
-        for kind, code, needs, defs in per_gap[g]:
-            if kind == "r":
-                hoist.append((g, 0, code, defs, min(LA, 2)))
-    hoist.sort(key=lambda h: (h[0], h[1]))
-    hp = [0]
-
-    def issue_upto(gap):
-        while hp[0] < len(hoist):
-            need, _, code, rn, ahead = hoist[hp[0]]
-            if need - ahead > gap or st.issued - st.done >= 13:
-                break
-            st.lds(code, rn)
-            hp[0] += 1
-
-    def force(rn):                          # a consumer is about to wait for rn: it must have been issued
-        while rn not in st.seq:
-            need, _, code, r2, ahead = hoist[hp[0]]
-            st.lds(code, r2)
-            hp[0] += 1
-
-    if xload:
-        st.lines.append("  if (c.has_next) { mw_static_for<20>([&](auto kc) { mw_load_x2<decltype(kc)::value, decltype(kc)::value>(c.xnext); "
-                        "mw_load_x2<20 + decltype(kc)::value, decltype(kc)::value>(c.xnext2); }); "
-                        "asm volatile(\"global_load_dwordx2 a[168:169], %0, off\\n\\tglobal_load_dwordx2 a[170:171], %0, off offset:256\" ::\"v\"(c.snext) : \"memory\"); }")
-    issue_upto(0)
-    for s in pre:
-        st.lines.append("  " + s)
-    for g in range(ngap):
-        code, rn, _ = mfs[g]
-        issue_upto(g)
-        force(rn)
-        st.stmt(code, [rn])
-        issue_upto(g + 1)
-        if g < len(rest):
-            st.lines.append("  " + rest[g])
-        for kind, ecode, needs, defs in per_gap[g]:
-            if kind == "r":
-                continue
-            for r in needs:
-                force(r)
-            if kind == "l":
-                for r in needs:
-                    st.wait(r)
-                st.lds(ecode, defs)
-            else:
-                st.stmt(ecode, needs)
-    for s in rest[ngap:]:
-        st.lines.append("  " + s)
-    for kind, ecode, needs, defs in per_gap[ngap]:
-        if kind == "r":
-            continue
-        for r in needs:
-            force(r)
-        if kind == "l":
-            for r in needs:
-                st.wait(r)
-            st.lds(ecode, defs)
-        else:
-            st.stmt(ecode, needs)
-    assert hp[0] == len(hoist), (name, hp[0], len(hoist))
-    st.lines.append("}")
-    return "\n".join(st.lines)
+    return schedule(decl, mf_items(mf) if mf else [], dma_pieces() if (mf and not NO_DMA) else [], items, LA, PRE_DMA, MAXV,
+                    top="if constexpr (RGM == 0) mw_wait_vm_barrier<VMC>();" if top else None, xload=xl if xload else None)
 
 
 def main():
-    parts = ["// GENERATED by tools/gen_qkvw_stream.py -- do not edit; see that script for the schedule rules.",
-             f"// LA = {LA} gaps of LDS-read lookahead, {PRE_DMA} LDS-DMA pieces in front of the first MFMA, <= {MAXV} epilogue statements per gap.", ""]
+    parts = header("gen_qkvw_stream.py", LA, PRE_DMA, MAXV)
     parts.append(build("qw_pro", None, "q", top=False))
     parts.append(build("qw_qq", "q", "q"))
     parts.append(build("qw_qv", "q", "v"))
     parts.append(build("qw_vv1", "v1", "v"))        # epilogue of a chunk's first V item (row group 0): RGM = 1 only
     parts.append(build("qw_vv0", "v2", "v"))        # epilogue of its second item: RGM = 0 only
     parts.append(build("qw_v_", "v2", None, xload=True))
-    txt = "\n\n".join(parts) + "\n"
-    if "-o" in sys.argv:
-        open(sys.argv[sys.argv.index("-o") + 1], "w").write(txt)
-        return
-    if "--check" in sys.argv:
-        cur = open(OUT).read() if os.path.exists(OUT) else ""
-        sys.exit(0 if cur == txt else 1)
-    open(OUT, "w").write(txt)
-    print("wrote", OUT, len(txt.split("\n")), "lines")
+    finish(parts, OUT)
 
 
 if __name__ == "__main__":

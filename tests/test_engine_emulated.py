@@ -17,11 +17,25 @@ from tests import cases
 from tests.emul_ops import EmulOps
 
 
+_SYNTH_CACHE = {}                            # one entry: (schema key) -> key-seeded state dict
+
+
+def _synth_sd(schema):
+    """synth.synth_state_dict(schema), kept for the next model of the same schema: the 1.228 B-parameter model's weights are 7 s of
+    CPU randn, and two dozen GPU tests build that model one after the other (load_state_dict COPIES: a test that edits its model
+    -- the first-conv swap, the fuser scale -- never touches the cached tensors)."""
+    key = hash(tuple(sorted(schema.items())))
+    if key not in _SYNTH_CACHE:
+        _SYNTH_CACHE.clear()
+        _SYNTH_CACHE[key] = synth.synth_state_dict(schema)
+    return _SYNTH_CACHE[key]
+
+
 def build_model(cfg, efficient_attention=True):
     with torch.device("meta"):
         m = UNetModel(**dict(unet_kwargs_from_cfg(cfg), efficient_attention=efficient_attention))
     m = m.to_empty(device="cpu")
-    m.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    m.load_state_dict(_synth_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}))
     return m.eval()
 
 

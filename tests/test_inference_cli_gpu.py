@@ -5,7 +5,12 @@ the CLI mirror runs demo JSON -> ``meta`` -> ``prepare_batch`` (+ ``prepare_inst
 Sampler) -> sampler -> VAE decode -> PNGs with ``--synthetic_weights`` (the full 1.228 B-parameter UNet, key-seeded weights; no
 trained weights exist offline), and the final latent is compared with the CPU oracle (``oracle/ref_cpu.py``: the restatement of
 the reference's samplers / UNet, pinned to the reference's goldens) run on the same meta, the same starting noise and the same
-weights.  Few steps and one image keep the oracle's share to tens of CPU forwards per case.
+weights.
+
+The oracle's side of that comparison is a committed fixture, ``tests/golden/cli_latents.pt`` (``python tests/make_cli_latents.py``:
+this module's ``_oracle_latent`` run once per case -- 12 to 28 full-size CPU forwards each, which on the GPU box's host cores was
+a third of the whole ``-m gpu`` suite's wall time, round 6).  ``IDF_CLI_LIVE_ORACLE=1`` runs the oracle live instead, as rounds
+5-6 did.
 """
 import json
 import os
@@ -53,16 +58,35 @@ def _oracle_latent(cfg_name, input_json, steps, mis, alpha, seed, negative_promp
     return lat, om.n_forward
 
 
-@pytest.mark.parametrize("name,cfg_name,input_json,mis", [
+CASES = [
     ("boxes + Multi-instance Sampler", "test_box.yaml", "demos/demo_four_boxes.json", 0.36),
     ("points", "test_point.yaml", "demos/demo_points.json", 0.0),
     ("scribbles", "test_scribble.yaml", "demos/demo_scribbles.json", 0.0),
-])
+]
+STEPS, ALPHA, SEED = 5, 0.8, 3
+DEFAULT_NEG = ("longbody, lowres, bad anatomy, bad hands, missing fingers, extra digit, fewer digits, cropped, worst quality, "
+               "low quality")                      # inference.py's --negative_prompt default (reference inference.py:171)
+FIXTURE = os.path.join(REPO, "tests", "golden", "cli_latents.pt")
+
+
+def _want(cfg_name, input_json, mis):
+    """(oracle latent, oracle forwards, source)"""
+    if os.environ.get("IDF_CLI_LIVE_ORACLE") == "1":
+        return _oracle_latent(cfg_name, input_json, STEPS, mis, ALPHA, SEED, DEFAULT_NEG) + ("run live",)
+    fx = torch.load(FIXTURE)
+    assert (fx["steps"], fx["alpha"], fx["seed"], fx["negative_prompt"]) == (STEPS, ALPHA, SEED, DEFAULT_NEG), \
+        "tests/golden/cli_latents.pt was made for other settings: re-run tests/make_cli_latents.py"
+    case = fx["cases"][cfg_name]
+    assert case["input_json"] == input_json and case["mis"] == mis
+    return case["latent"], case["n_forward"], "fixture"
+
+
+@pytest.mark.parametrize("name,cfg_name,input_json,mis", CASES)
 def test_inference_cli_end_to_end_matches_oracle(tmp_path, monkeypatch, capsys, name, cfg_name, input_json, mis):
     import inference
     from PIL import Image
     from tests import cases
-    steps, alpha, seed = 5, 0.8, 3
+    steps, alpha, seed = STEPS, ALPHA, SEED
     out_dir = tmp_path / "OUT"
     argv = ["inference.py", "--synthetic_weights", "--num_images", "1", "--steps", str(steps), "--mis", str(mis), "--alpha", str(alpha),
             "--seed", str(seed), "--input_json", os.path.join(REPO, input_json), "--test_config", os.path.join(REPO, "configs", cfg_name),
@@ -81,10 +105,8 @@ def test_inference_cli_end_to_end_matches_oracle(tmp_path, monkeypatch, capsys, 
     saved = torch.load(folder / "latents.pt")
     lat = saved["latents"].float()
     assert tuple(lat.shape) == (1, 4, 64, 64) and torch.isfinite(lat).all()
-    default_neg = ("longbody, lowres, bad anatomy, bad hands, missing fingers, extra digit, fewer digits, cropped, worst quality, "
-                   "low quality")
-    want, n_fwd = _oracle_latent(cfg_name, input_json, steps, mis, alpha, seed, default_neg)
+    want, n_fwd, src = _want(cfg_name, input_json, mis)
     err = cases.rel_rms(lat, want)
     print(f"[parity] inference.py end to end, {name} ({cfg_name}, S={steps}, mis={mis}): latent rel-rms {err:.3e} vs the CPU oracle "
-          f"({n_fwd} oracle forwards; tol 5e-2), image {img.size}")
+          f"({n_fwd} oracle forwards, {src}; tol 5e-2), image {img.size}")
     assert err < 5e-2

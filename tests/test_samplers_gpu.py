@@ -162,13 +162,17 @@ def test_mis_crop_and_paste_on_gpu_vs_oracle():
             oin.append(dict(x=inp["x"].clone(), timesteps=None, context=inp["inst_ctx"][i],
                             grounding_input=ref_cpu.prepare_grounding(synth.instance_batch(inp["gb"], i))))
         want = ref_cpu.plms_sample_mis(om, S, oin, inp["uc"], 7.5, mis, alpha_type=at, crop_and_paste=True)
-        plain = ref_cpu.plms_sample_mis(ref_cpu.OracleModel(sd, cfg, synth.synth_first_conv_sd()), S,
-                                        [dict(d, x=inp["x"].clone()) for d in oin], inp["uc"], 7.5, mis, alpha_type=at)
-    assert cases.rel_rms(want, plain) > 1e-2, "the two merge modes must differ on this case for the test to mean anything"
-    sampler = PLMSSamplerInst(diffusion, model, alpha_generator_func=partial(alpha_generator, type=at),
-                              set_alpha_scale=set_alpha_scale, mis=mis, crop_and_paste_latents=True)
-    out = sampler.sample(S=S, shape=tuple(inp["x"].shape), input=_mis_inputs(inp, gi, meta), uc=inp["uc"].cuda(),
-                         guidance_scale=7.5)
+
+    def hip(crop):
+        # (a sampling run leaves its model with the first conv swapped, as the reference does: a fresh one per run)
+        _, _, _, m, gi_m, _ = _setup("tiny_box")
+        sampler = PLMSSamplerInst(diffusion, m, alpha_generator_func=partial(alpha_generator, type=at),
+                                  set_alpha_scale=set_alpha_scale, mis=mis, crop_and_paste_latents=crop)
+        return sampler.sample(S=S, shape=tuple(inp["x"].shape), input=_mis_inputs(inp, gi_m, meta), uc=inp["uc"].cuda(),
+                              guidance_scale=7.5)
+    out, plain = hip(True), hip(False)
+    # (round 6: the averaging run of this check used to be a second live oracle trajectory -- half of the slowest test of the suite)
+    assert cases.rel_rms(out.cpu(), plain.cpu()) > 1e-2, "the two merge modes must differ on this case for the test to mean anything"
     err = cases.rel_rms(out.cpu(), want)
     print(f"[parity] tiny_box MIS crop-and-paste S={S}: latent rel-rms {err:.3e} (tol {TRAJ_TOL[torch.bfloat16]:.0e})")
     assert torch.isfinite(out).all() and err < TRAJ_TOL[torch.bfloat16]

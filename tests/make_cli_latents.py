@@ -19,7 +19,7 @@ sys.path.insert(0, REPO)
 
 def main():
     from tests import test_inference_cli_gpu as t
-    out = dict(steps=t.STEPS, alpha=t.ALPHA, seed=t.SEED, negative_prompt=t.DEFAULT_NEG, torch=torch.__version__, cases={})
+    out = dict(steps=t.STEPS, alpha=t.ALPHA, seed=t.SEED, negative_prompt=t.DEFAULT_NEG, torch=str(torch.__version__), cases={})
     for name, cfg_name, input_json, mis in t.CASES:
         t0 = time.time()
         lat, n = t._oracle_latent(cfg_name, input_json, t.STEPS, mis, t.ALPHA, t.SEED, t.DEFAULT_NEG)

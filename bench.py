@@ -276,10 +276,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images-per-gpu", type=int, default=32)  # 32 images x (8+1) trajectories = 288 units per MIS step
-    ap.add_argument("--max-units", type=int, default=64,
-                    help="MIS phase-1 (instance, image) units per batched forward: 64 units x cond/uncond = 128-row forwards (4 of them + one "
-                         "64-row forward per MIS step at 32 images; 1.42 ms per row against 1.47 at 64 rows, "
-                         "profiles/r03_bench_width_ab.json); phase 2 runs 64-row forwards (one row pair per image)")
+    ap.add_argument("--max-units", type=int, default=128,
+                    help="MIS phase-1 (instance, image) units per batched forward (PLMSSamplerInst's default): 128 units x cond/uncond = "
+                         "256-row forwards (2 of them + one 64-row forward per MIS step at 32 images; 1.230 ms per row against 1.250 at 128 "
+                         "rows, profiles/r06_replay_256.log; 2.037 against 2.013 img/s same-box, profiles/r06_maxunits_ab.log); phase 2 runs "
+                         "64-row forwards (one row pair per image)")
     ap.add_argument("--images-total", type=int, default=0,
                     help="strong scaling: fix the GLOBAL images per step (split over the ranks) instead of images per GPU")
     ap.add_argument("--sharding", choices=["auto", "image", "instance"], default="instance",

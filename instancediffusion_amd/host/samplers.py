@@ -173,7 +173,7 @@ class PLMSSamplerInst(_PLMSBase):
     """Multi-instance Sampler, plms_instance.py:7-212."""
 
     def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None, mis=0.0,
-                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 64,
+                 crop_and_paste_latents=False, shard_across_ranks: Optional[bool] = None, max_units: int = 128,
                  unit_sharding: str = "auto"):
         super().__init__(diffusion, model, schedule, alpha_generator_func, set_alpha_scale)
         self.mis = mis
@@ -181,6 +181,8 @@ class PLMSSamplerInst(_PLMSBase):
         self.shard_across_ranks = shard_across_ranks
         assert unit_sharding in ("auto", "image", "instance")
         self.unit_sharding = unit_sharding
+        # phase-1 (instance, image) units per batched forward: 128 units x [cond | uncond] = 256-row forwards (1.230 ms per row
+        # against 1.250 at 128 rows and 1.27 at 64, graph-replayed: profiles/r06_replay_256.log; bench + 1.2 %, r06_maxunits_ab.log)
         self.max_units = max_units
 
     @torch.no_grad()

@@ -199,8 +199,9 @@ def _stat(which):
 
 def _forward_at_bench_width(tag, dtype, rows=64, min_big=150, min_att=10):
     """The forward the BENCH runs: `rows` = rows/2 conditional + rows/2 null-grounding rows, as PLMSSamplerInst forms them
-    (host/samplers.py: one [cond | uncond] batch per `max_units` units; the bench's default max_units = 64 gives the 128-row
-    phase-1 forwards, its phase-2 forwards have 64 rows), with DEFAULT dispatch.  Every engine / sampler golden is a
+    (host/samplers.py: one [cond | uncond] batch per `max_units` units; the bench's default max_units = 128 gives the 256-row
+    phase-1 forwards, its phase-2 forwards -- and the last phase-1 chunk of 32 images -- have 64 rows; 128 rows = max_units 64, the
+    default of rounds 3-5), with DEFAULT dispatch.  Every engine / sampler golden is a
     batch-1..3 forward whose tile grids fail the persistent kernel's round-efficiency gate (gemm_big.hip), so those run the
     128^2 fallback kernels; here M = rows x H x W and the counters must show that ``gemm_kernel_big`` and the 64-query
     LDS-DMA attention served the launches (the two widths differ in tile grids and in the 8x8-level split-K factor).  The
@@ -250,11 +251,12 @@ def _forward_at_bench_width(tag, dtype, rows=64, min_big=150, min_att=10):
     _check(eps[n:n + 1], gold["eps_uncond"], f"{tag} {rows}-row forward (default dispatch), uncond rows", tag, dtype, survey_bar=True)
 
 
-@pytest.mark.parametrize("rows", [64, 128])
+@pytest.mark.parametrize("rows", [64, 128, 256])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_full_size_forward_at_bench_width_default_dispatch(dtype, rows):
-    """Parity at the kernel selection the bench runs (full 1.228 B model, 64x64 latent, C1 golden): 128 rows = the MIS
-    phase-1 forwards of the default bench (max_units 64), 64 rows = its phase-2 forwards."""
+    """Parity at the kernel selection the bench runs (full 1.228 B model, 64x64 latent, C1 golden): 256 rows = the MIS
+    phase-1 forwards of the default bench (max_units 128; M = 2^20 rows at the 64^2 level: the largest index ranges any launch of the
+    repo forms), 64 rows = its phase-2 forwards, 128 rows = phase 1 with ``--max-units 64`` (the default of rounds 3-5)."""
     _forward_at_bench_width("full_box_c1", dtype, rows)
 
 

@@ -184,8 +184,8 @@ def test_full_model_headline_trajectory_s50_n8_at_bench_width(dtype):
     ``PLMSSamplerInst`` (plms_instance.py:59-158) on the full 1.228 B-parameter UNet, B = 1, 64x64 latent, S = 50
     (inference.py:64), N = 8 boxes, mis 0.36, alpha [0.8, 0, 0.2] with the first-conv swap at step 40, CFG 7.5: 406 chained
     CPU forwards (``oracle/make_golden.py --only full_s50``).  Here the same inputs are replicated to 32 images so that the
-    sampler forms exactly the bench's forwards (``PLMSSamplerInst``'s default ``max_units`` = 64: 288 (instance, image)
-    units in chunks of 64 = 128-row phase-1 forwards with 4096 + 184 keys in the d = 40 attention -- the last chunk has 32
+    sampler forms exactly the bench's forwards (``PLMSSamplerInst``'s default ``max_units`` = 128: 288 (instance, image)
+    units in chunks of 128 = 256-row phase-1 forwards with 4096 + 184 keys in the d = 40 attention -- the last chunk has 32
     units = 64 rows -- and 64-row phase-2 forwards; default dispatch, hipGraph replay).  Besides the final latent, the merged
     latent (the mean over the N+1 instance latents after 18 steps) is compared with the reference's."""
     from instancediffusion_amd import _lib
@@ -224,7 +224,7 @@ def test_full_model_headline_trajectory_s50_n8_at_bench_width(dtype):
     spread = max(cases.rel_rms(out_c[i:i + 1], out_c[:1]) for i in range(1, R))
     err = cases.rel_rms(out_c[:1], gold["mis"])
     err_m = cases.rel_rms(seen["merged"][:1].float().cpu(), gold["marks"]["merged"])
-    print(f"[parity] full model MIS S=50 N=8 mis=0.36 alpha [0.8,0,0.2] {dtype}, 32 images (128-row phase-1 / 64-row phase-2 forwards): final latent "
+    print(f"[parity] full model MIS S=50 N=8 mis=0.36 alpha [0.8,0,0.2] {dtype}, 32 images (256- and 64-row phase-1 / 64-row phase-2 forwards): final latent "
           f"rel-rms {err:.3e} (tol {TRAJ_TOL[dtype]:.0e}), merged latent after 18 steps {err_m:.3e}; the 32 identical images "
           f"{'are bitwise equal' if same else f'differ by {spread:.2e}'}")
     assert err < TRAJ_TOL[dtype] and err_m < TRAJ_TOL[dtype]

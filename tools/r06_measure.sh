@@ -3,6 +3,9 @@
 #   part = bench   : smoke, default bench line, rocprofv3 kernel-trace summary of the bench command
 #   part = pmc     : FETCH_SIZE / WRITE_SIZE passes + eager kernel stats at 128 rows, norm bandwidth table, shape profile, SQ counters
 #                    of the attention kernels (torch-free harness)
+#   part = b256    : end of round 6, the sampler's default max_units 64 -> 128 (256-row phase-1 forwards): the headline-trajectory test
+#                    (32 identical images through 256- and 64-row forwards must stay bitwise equal), PMC passes + kernel stats at 256 rows
+#                    folded into profiles/pmc_traffic.json["256"], rocprofv3 kernel-trace summary of the bench command, default bench line
 #   part = configs : other BASELINE configs, graph-replay times per forward width, 2-rank gloo bench on one GPU
 # (the GPU test suite is its own call: tools/gpu_call.sh r06_gpu_suite 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider)
 set -x
@@ -30,6 +33,26 @@ if [ "$PART" = pmc ]; then
   ( cd /tmp && HARNESS_REPS=2 HARNESS_ATTN8=1 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/attn_write -- $R/tools/ubench/attn_harness $R/instancediffusion_amd/libidf_gfx950.so 128 1,4,5 > $O/attn_write.log 2>&1 )
   python tools/sq_counters.py $O/attn_sq_summary.csv $O/attn_sq --match attn > $O/attn_sq_summary.txt 2>&1; cat $O/attn_sq_summary.txt | cut -c1-250
   python tools/pmc_summary.py $O/attn_fetch $O/attn_write 128 $O/attn_pmc_traffic.json > $O/attn_pmc_summary.log 2>&1; grep -i attn $O/attn_pmc_summary.log | cut -c1-200
+fi
+if [ "$PART" = b256 ]; then
+  O=$R/gpurun_out/r06_b256; mkdir -p $O
+  timeout 300 python -m pytest tests/test_samplers_gpu.py -q -m gpu -s -k "headline_trajectory_s50_n8_at_bench_width" > $O/headline_256.log 2>&1; grep -h "parity\|passed\|failed" $O/headline_256.log | cut -c1-400
+  ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/tools/profile_forward.py 256 2 > $O/pmc_fetch.log 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/tools/profile_forward.py 256 2 > $O/pmc_write.log 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_fwd -- python $R/tools/profile_forward.py 256 3 > $O/fwd_stats.log 2>&1 )
+  python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 256 $O/pmc_traffic_b256.json $O/pmc_traffic_table.json > $O/pmc_summary.log 2>&1; tail -8 $O/pmc_summary.log
+  python - <<PY
+import json
+tab = json.load(open("$O/pmc_traffic_table.json"))["256"]
+for v in tab.values():
+    v["source"] = "r06_rocprof/pmc_traffic_b256.json"
+p = "$R/profiles/pmc_traffic.json"
+d = json.load(open(p)); d["256"] = tab
+json.dump(d, open(p, "w"), indent=1)
+json.dump(d, open("$O/pmc_traffic_merged.json", "w"), indent=1)
+PY
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-ref-batch-leg > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err )
+  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
 fi
 if [ "$PART" = dtype ]; then
   # fp16 vs bf16, kernel by kernel, on ONE box back to back: eager 128-row forwards under the kernel trace

@@ -16,7 +16,8 @@ Row widths that were not measured are interpolated linearly between the neighbou
 import json
 import sys
 
-N_INST, S, MIS, MAX_UNITS = 8, 50, 0.36, 64
+N_INST, S, MIS, MAX_UNITS = 8, 50, 0.36, 64       # (the sampler's default is 128 since the end of round 6: the committed prediction
+                                                    #  tables were made with 64; for 128 add a measured "256" width to the input)
 
 
 def interp(tab, rows):

@@ -190,6 +190,13 @@ class PLMSSamplerInst(_PLMSBase):
         self.make_schedule(ddim_num_steps=S)
         return self.plms_sampling(shape, input, uc, guidance_scale, mask=mask, x0=x0)
 
+    @staticmethod
+    def units_per_forward(max_units: int, h: int, w: int) -> int:
+        """(instance, image) units per phase-1 forward: ``max_units`` at latents up to 64 x 64; beyond (C4: 96 x 96) the same TOKEN
+        budget per forward (2 max_units x 4096 rows of the 64^2 level: 2^20 at the default, the width every kernel's index ranges
+        are tested at), but never fewer than the 64 units the default of rounds 3-6 formed at every size."""
+        return min(max_units, max(64, max_units * 4096 // (h * w)))
+
     # ---- distributed helpers ----------------------------------------------------------------------------
     def _dist(self):
         import torch.distributed as dist
@@ -292,10 +299,11 @@ class PLMSSamplerInst(_PLMSBase):
         # instances would run their EARLY steps with the swapped conv.  Only then is the serial order observable;
         # reproduce it by advancing one instance at a time.
         serial = alphas is not None and any(alphas[i] == 0 for i in range(mis_step))
+        per_fwd = self.units_per_forward(self.max_units, int(shape[2]), int(shape[3]))
         if serial:
             chunks = [[u for u in units if u[0] == j] for j in range(n_all)]
         else:
-            chunks = [units[k:k + self.max_units] for k in range(0, len(units), self.max_units)]
+            chunks = [units[k:k + per_fwd] for k in range(0, len(units), per_fwd)]
         x_units: Dict[tuple, torch.Tensor] = {}
         eps_units: Dict[tuple, list] = {}
         same_start = all(inp["x"] is input_all[0]["x"] or torch.equal(inp["x"], input_all[0]["x"]) for inp in input_all[1:])
@@ -314,7 +322,7 @@ class PLMSSamplerInst(_PLMSBase):
             first_idx = {u: k for k, u in enumerate(units)}
             first_unc = {b: len(units) + k for k, b in enumerate(imgs)}
             x0_all = input_all[0]["x"].to(dev, torch.float32)
-            width = 2 * self.max_units
+            width = 2 * per_fwd
             parts = []
             for k in range(0, len(row_ids), width):
                 r = torch.tensor(row_ids[k:k + width], device=dev, dtype=torch.long)

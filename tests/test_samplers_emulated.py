@@ -353,3 +353,15 @@ def test_mis_sampler_issues_two_collectives_and_one_broadcast_per_sample_gloo():
         assert given == {"all_gather": 2}, (rank, given)
         assert drawn == {"broadcast": 1, "all_gather": 2}, (rank, drawn)
     assert (res[0][1] == res[1][1]).all()
+
+
+def test_units_per_forward_keeps_the_token_budget_above_64x64_latents():
+    """The sampler's default forms 256-row phase-1 forwards at 64 x 64 (128 units); at larger latents the forward keeps the 64^2
+    case's token count instead of its row count, and never drops below the 64 units of the earlier default."""
+    from instancediffusion_amd.host.samplers import PLMSSamplerInst
+    f = PLMSSamplerInst.units_per_forward
+    assert f(128, 64, 64) == 128 and f(128, 32, 32) == 128
+    assert f(128, 96, 96) == 64 and f(128, 128, 128) == 64
+    assert f(256, 96, 96) == 113 and f(64, 96, 96) == 64 and f(32, 96, 96) == 32
+    import inspect
+    assert inspect.signature(PLMSSamplerInst.__init__).parameters["max_units"].default == 128

@@ -197,6 +197,19 @@ class PLMSSamplerInst(_PLMSBase):
         are tested at), but never fewer than the 64 units the default of rounds 3-6 formed at every size."""
         return min(max_units, max(64, max_units * 4096 // (h * w)))
 
+    @staticmethod
+    def chunk_sizes(n_units: int, per_fwd: int):
+        """Phase-1 forwards of a rank's n_units: full ones of per_fwd units, then the remainder -- cut at a multiple of 64 units when
+        it is larger than that: 128-row multiples fill the persistent kernels' tile grids (2 / 4 full rounds of the 32^2 level's
+        256-row tiles on 256 CUs), widths in between do not (72 units as ONE 144-row forward ran the 8-image bench leg 3 % slower
+        than 64 + 8: profiles/r06_bench_final.json against r06_bench_final_maxunits64_*.json)."""
+        out, left = [], n_units
+        while left > 0:
+            n = per_fwd if left >= per_fwd else (left if left <= 64 or left % 64 == 0 else left // 64 * 64)
+            out.append(n)
+            left -= n
+        return out
+
     # ---- distributed helpers ----------------------------------------------------------------------------
     def _dist(self):
         import torch.distributed as dist
@@ -303,7 +316,10 @@ class PLMSSamplerInst(_PLMSBase):
         if serial:
             chunks = [[u for u in units if u[0] == j] for j in range(n_all)]
         else:
-            chunks = [units[k:k + per_fwd] for k in range(0, len(units), per_fwd)]
+            chunks, k = [], 0
+            for n in self.chunk_sizes(len(units), per_fwd):
+                chunks.append(units[k:k + n])
+                k += n
         x_units: Dict[tuple, torch.Tensor] = {}
         eps_units: Dict[tuple, list] = {}
         same_start = all(inp["x"] is input_all[0]["x"] or torch.equal(inp["x"], input_all[0]["x"]) for inp in input_all[1:])

@@ -365,3 +365,11 @@ def test_units_per_forward_keeps_the_token_budget_above_64x64_latents():
     assert f(256, 96, 96) == 113 and f(64, 96, 96) == 64 and f(32, 96, 96) == 32
     import inspect
     assert inspect.signature(PLMSSamplerInst.__init__).parameters["max_units"].default == 128
+    c = PLMSSamplerInst.chunk_sizes
+    assert c(288, 128) == [128, 128, 32]            # the bench: 32 images x 9 trajectories
+    assert c(72, 128) == [64, 8]                    # its 8-image leg: not one 144-row forward
+    assert c(72, 64) == [64, 8] and c(9, 128) == [9] and c(0, 128) == [] and c(128, 128) == [128] and c(64, 128) == [64]
+    assert c(200, 128) == [128, 64, 8] and c(192, 128) == [128, 64] and c(100, 32) == [32, 32, 32, 4]
+    for n in range(0, 400, 7):
+        for m in (1, 32, 64, 113, 128, 256):
+            assert sum(c(n, m)) == n and all(0 < k <= m for k in c(n, m))
